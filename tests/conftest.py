@@ -1,0 +1,33 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+def split(cat, off):
+    return [cat[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+
+
+# stated parity tolerance of a relative pose vs the float64 reference
+TOL_TRANS = 5e-5      # metres
+TOL_ROT = 5e-6        # radians (checked on the rotation-matrix entries)
