@@ -1,0 +1,175 @@
+/*
+ * lslam.h — C ABI of the MI355X (gfx950) ICP scan-matching / occupancy-grid engine.
+ *
+ * The reference (fadli0029/LiDAR-SLAM) is pure Python and has no FFI layer; its
+ * boundary for this path is the function surface of modules/icp.py and
+ * modules/ogm.py.  Every entry point below names the reference interface it
+ * replaces (paths relative to the reference root).  The binding a maintainer of
+ * the reference would add is a ctypes.CDLL stub — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - every function returns LSLAM_OK (0) or a negative LSLAM_ERR_* code and
+ *     records a message retrievable with lslam_last_error() (thread-local);
+ *   - point clouds are float32, row-major (n, dim) with dim = 2 (planar scans,
+ *     the reference pads z = 0: modules/icp.py:153-156) or 3;
+ *   - transforms are float64 4x4 row-major, exactly numpy's C layout of the
+ *     reference's matrices;
+ *   - "_dev" functions take DEVICE pointers (hipMalloc / torch.Tensor.data_ptr())
+ *     plus a hipStream_t passed as void*; they enqueue work and return without
+ *     synchronising.  The others take HOST pointers, use library-owned device
+ *     scratch and return when the results are in the caller's buffers;
+ *   - the caller owns every input and output buffer; inputs are never written.
+ *
+ * There is no CPU fallback: on a machine without a HIP device every compute
+ * entry point fails with LSLAM_ERR_HIP.
+ */
+#ifndef LSLAM_H
+#define LSLAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSLAM_OK                 0
+#define LSLAM_ERR_BAD_ARG      (-1)  /* NULL pointer, bad dim, negative size, non-monotone offsets ...      */
+#define LSLAM_ERR_EMPTY_TARGET (-2)  /* reference: IndexError from pc2[correspondences] (icp.py:118)        */
+#define LSLAM_ERR_NONFINITE    (-3)  /* reference: ValueError "'x' must be finite" from KDTree (icp.py:161) */
+#define LSLAM_ERR_HIP          (-4)  /* any HIP runtime failure, including "no device"                      */
+
+#define LSLAM_ABI_VERSION 1
+
+/* ---- housekeeping ------------------------------------------------------ */
+int         lslam_abi_version(void);
+const char *lslam_last_error(void);
+/* number of visible HIP devices, 0 if none, never fails */
+int         lslam_device_count(void);
+/* bind the calling host thread to a device (one host thread / process per GPU) */
+int         lslam_set_device(int device);
+
+/* ---- ICP: modules/icp.py:123-189 run_icp, batched ---------------------- */
+/*
+ * S independent point-to-point ICP problems in one launch (one workgroup per
+ * problem, on-chip until converged).  Problem s aligns the source points
+ * src[src_off[s] .. src_off[s+1]) to the target points tgt[tgt_off[s] .. tgt_off[s+1]).
+ * (Offsets count POINTS, not floats.)  src and tgt may alias the same buffer:
+ * for a scan sequence pass the scans once and src_off = off + 1, tgt_off = off
+ * (source = scan i, target = scan i-1: modules/localization.py:120-123).
+ *
+ * Per problem this is run_icp(pc1, pc2, init_transform, epsilon, max_iters,
+ * stopping_thresh, normalize_error=...) with the reference's stop rules in the
+ * reference's order (icp.py:172-181) and its "error of the pre-update residual"
+ * convention (icp.py:116-120).
+ *
+ *   init_T     S x 16 float64, row-major 4x4 per problem (icp.py:125)
+ *   out_T      S x 16 float64
+ *   out_err    S float64    error measured in the last executed iteration (icp.py:120)
+ *   out_iters  S int32      number of icp_iteration calls executed
+ *   out_corr   NULL, or int32 per source point laid out like src_off: index (relative to
+ *              the problem's target) matched in the LAST iteration (icp.py:117, 187-189)
+ *   flags      LSLAM_ICP_* bits
+ */
+#define LSLAM_ICP_NORMALIZE_ERROR 1u   /* icp.py:91-97 */
+
+int lslam_icp_batch(const float *src, const int64_t *src_off,
+                    const float *tgt, const int64_t *tgt_off,
+                    int dim, const double *init_T, int32_t S,
+                    double epsilon, double stopping_thresh, int32_t max_iters,
+                    uint32_t flags,
+                    double *out_T, double *out_err, int32_t *out_iters,
+                    int32_t *out_corr, int device);
+
+/* Same, all pointers on the device; max_src_n / max_tgt_n bound the per-problem
+ * sizes (they fix the launch geometry; the offsets are only read on the device).
+ * Inputs are trusted to be finite and every target non-empty (the host entry
+ * point validates; this one cannot without a synchronisation). */
+int lslam_icp_batch_dev(const float *d_src, const int64_t *d_src_off,
+                        const float *d_tgt, const int64_t *d_tgt_off,
+                        int dim, const double *d_init_T, int32_t S,
+                        int64_t max_src_n, int64_t max_tgt_n,
+                        double epsilon, double stopping_thresh, int32_t max_iters,
+                        uint32_t flags,
+                        double *d_out_T, double *d_out_err, int32_t *d_out_iters,
+                        int32_t *d_out_corr, void *stream);
+
+/* ---- ICP on ONE large cloud pair (whole chip on one problem) ------------ */
+/*
+ * run_icp for clouds too large for one workgroup (config "100k x 100k"): per
+ * iteration a grid-wide LDS-tiled nearest-neighbour pass, a moment reduction
+ * and a device-side solve; convergence is decided on the device, the host only
+ * polls a flag every `poll_every` iterations.  d_src/d_tgt: device pointers.
+ * init_T / out_T / out_err / out_iters: HOST pointers.  d_out_corr: device, or NULL.
+ */
+int lslam_icp_large_dev(const float *d_src, int64_t n, const float *d_tgt, int64_t m,
+                        int dim, const double *init_T,
+                        double epsilon, double stopping_thresh, int32_t max_iters,
+                        uint32_t flags, int32_t poll_every,
+                        double *out_T, double *out_err, int32_t *out_iters,
+                        int32_t *d_out_corr, void *stream);
+
+/* Same with HOST clouds (float32, validated: finite, non-empty target) and HOST out_corr
+ * (n int32 or NULL); copies through library-owned device scratch. */
+int lslam_icp_large(const float *src, int64_t n, const float *tgt, int64_t m,
+                    int dim, const double *init_T,
+                    double epsilon, double stopping_thresh, int32_t max_iters,
+                    uint32_t flags,
+                    double *out_T, double *out_err, int32_t *out_iters,
+                    int32_t *out_corr, int device);
+
+/* ---- single operators of modules/icp.py -------------------------------- */
+/* get_correspondences (icp.py:29-41) after the homogeneous transform of icp.py:116:
+ * for every source point the index of the nearest target point (exact float32
+ * direct-difference distance, lowest index on ties).  T: HOST 4x4 float64 or NULL
+ * (identity).  d_out_idx: n int32; d_out_d2: n float32 squared distances or NULL. */
+int lslam_nn_dev(const float *d_src, int64_t n, const float *d_tgt, int64_t m, int dim,
+                 const double *T, int32_t *d_out_idx, float *d_out_d2, void *stream);
+
+/* Same with HOST pointers (validated like lslam_icp_large). */
+int lslam_nn(const float *src, int64_t n, const float *tgt, int64_t m, int dim,
+             const double *T, int32_t *out_idx, float *out_d2, int device);
+
+/* get_transform (icp.py:43-74): Kabsch rigid transform taking rows of p onto rows
+ * of q.  p, q: HOST float64, n rows, row strides in doubles (>= 3; the reference
+ * passes (N,4) homogeneous arrays and uses [:, 0:3]).  out_T: 16 float64. */
+int lslam_kabsch(const double *p, int64_t p_stride, const double *q, int64_t q_stride,
+                 int64_t n, double *out_T, int device);
+
+/* get_error (icp.py:76-98): sum of squared distances of paired rows; with normalize
+ * != 0 divided by (joint bounding-box diagonal)^2 * n.  p, q: HOST float64, n x cols
+ * contiguous (cols = 3 in the reference). */
+int lslam_sq_error(const double *p, const double *q, int64_t n, int32_t cols,
+                   int32_t normalize, double *out_err, int device);
+
+/* ---- occupancy grid: modules/ogm.py ------------------------------------- */
+/* OccupancyGridMap state (ogm.py:37-43) resident in HBM: float32 log-odds
+ * (width x height, indexed [x_cell][y_cell], ogm.py:41) plus an int32 hit/miss
+ * scratch grid. */
+int lslam_ogm_create(double res, double world_min_x, double world_min_y,
+                     int32_t width, int32_t height, double logodds_step, double logodds_clip,
+                     int device, void **out_handle);
+int lslam_ogm_destroy(void *handle);
+/* the reference keeps the step in a public attribute (ogm.py:43 logodds_ratio) */
+int lslam_ogm_set_params(void *handle, double logodds_step, double logodds_clip);
+
+/* update_map (ogm.py:149-188) for K scans applied IN ORDER (the per-scan clip makes
+ * the order matter).  poses: K x 3 float64 (x, y, yaw); scan k is the (n_k, 2)
+ * float64 robot-frame points scans_xy[scan_off[k] .. scan_off[k+1]).  HOST pointers. */
+int lslam_ogm_update(void *handle, const double *poses, const double *scans_xy,
+                     const int64_t *scan_off, int32_t K);
+
+/* The integer (hits - misses) grid ONE scan would add, without touching the
+ * log-odds: the bit-exact contract for cell indices (ogm.py:169-185).  out: width*height int32. */
+int lslam_ogm_scan_counts(void *handle, const double *pose, const double *scan_xy,
+                          int32_t n, int32_t *out_counts);
+
+int lslam_ogm_read_logodds(void *handle, float *out);         /* width*height float32 */
+int lslam_ogm_write_logodds(void *handle, const float *in);
+/* build_map's binarisation (ogm.py:61-64): 1 where 1/(1+exp(l)) > 0.5 else 0 */
+int lslam_ogm_binarize(void *handle, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSLAM_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of ``liblslam_hip.so`` (the C ABI of ``include/lslam.h``)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblslam_hip.so")
+
+OK, ERR_BAD_ARG, ERR_EMPTY_TARGET, ERR_NONFINITE, ERR_HIP = 0, -1, -2, -3, -4
+ICP_NORMALIZE_ERROR = 1
+
+
+class LslamError(RuntimeError):
+    """A HIP failure (no device, launch error, out of memory) reported by the library."""
+
+
+_lib = None
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+
+# name -> (restype, argtypes); mirrors include/lslam.h line by line
+SIGNATURES = {
+    "lslam_abi_version": (C.c_int, []),
+    "lslam_last_error": (C.c_char_p, []),
+    "lslam_device_count": (C.c_int, []),
+    "lslam_set_device": (C.c_int, [C.c_int]),
+    "lslam_icp_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_uint32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "lslam_icp_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_int32, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int32,
+                                      C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "lslam_icp_large_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                      C.c_double, C.c_double, C.c_int32, C.c_uint32, C.c_int32, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lslam_icp_large": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_double,
+                                  C.c_double, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int]),
+    "lslam_nn": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                           C.c_void_p, C.c_int]),
+    "lslam_nn_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lslam_kabsch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int]),
+    "lslam_sq_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int]),
+    "lslam_ogm_create": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double,
+                                   C.c_double, C.c_int, C.POINTER(C.c_void_p)]),
+    "lslam_ogm_destroy": (C.c_int, [C.c_void_p]),
+    "lslam_ogm_set_params": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "lslam_ogm_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "lslam_ogm_scan_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "lslam_ogm_read_logodds": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lslam_ogm_write_logodds": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lslam_ogm_binarize": (C.c_int, [C.c_void_p, C.c_void_p]),
+}
+
+
+def lib():
+    """Load the shared library once.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LslamError(
+            f"{LIB_PATH} is missing: build it with `make -C lidar_slam_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # When torch is (or will be) in the process, its bundled libamdhip64 must be the one HIP
+    # runtime both sides use: it has the same SONAME, so loading torch first makes ours bind to it.
+    if "torch" not in sys.modules and os.environ.get("LSLAM_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    return lib().lslam_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    """Map a C status to the exception the reference raises for the same input."""
+    if rc == OK:
+        return
+    msg = last_error()
+    if rc == ERR_EMPTY_TARGET:
+        raise IndexError(msg)                    # reference: pc2[correspondences] on an empty cloud
+    if rc == ERR_NONFINITE:
+        raise ValueError(msg)                    # reference: KDTree "'x' must be finite"
+    if rc == ERR_BAD_ARG:
+        raise ValueError(msg)
+    raise LslamError(msg or f"lslam error {rc}")
+
+
+def device_count() -> int:
+    return int(lib().lslam_device_count())
+
+
+def ptr(a):
+    """ctypes void* of a C-contiguous numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)

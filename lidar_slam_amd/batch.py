@@ -1,0 +1,90 @@
+"""Batched ICP over the C ABI: host-array and device-resident entry points."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, ptr
+
+
+@dataclass
+class IcpBatchResult:
+    T: np.ndarray            # (S,4,4) float64
+    error: np.ndarray        # (S,) float64
+    iterations: np.ndarray   # (S,) int32
+    correspondences: np.ndarray | None = None   # (total_src,) int32, CSR like src_off
+
+
+def pack_clouds(clouds):
+    """list of (n_i, d) arrays -> (float32 (Σn_i, d) C-contiguous, int64 offsets (len+1,))"""
+    d = clouds[0].shape[1] if len(clouds) else 2
+    off = np.zeros(len(clouds) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([c.shape[0] for c in clouds])
+    flat = np.empty((int(off[-1]), d), dtype=np.float32)
+    for c, a, b in zip(clouds, off[:-1], off[1:]):
+        if c.shape[1] != d:
+            raise ValueError("all clouds of a batch must have the same dimension")
+        flat[a:b] = c
+    return flat, off
+
+
+def icp_batch(src, src_off, tgt, tgt_off, init_T, epsilon=0.01, max_iters=2000, stopping_thresh=0.0001,
+              normalize_error=False, return_correspondences=False, device=0) -> IcpBatchResult:
+    """S independent run_icp problems (modules/icp.py:123-189) in one launch, host arrays in/out.
+
+    src, tgt: float32 (N,d) packed clouds (d = 2 or 3; they may be the same array for a scan
+    sequence); src_off, tgt_off: int64 (S+1,) point offsets; init_T: (S,4,4) float64."""
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    tgt = src if tgt is src else np.ascontiguousarray(tgt, dtype=np.float32)
+    if src.ndim != 2 or src.shape[1] not in (2, 3) or tgt.ndim != 2 or tgt.shape[1] != src.shape[1]:
+        raise ValueError("clouds must be (N,2) or (N,3) with equal dimension")
+    src_off = np.ascontiguousarray(src_off, dtype=np.int64)
+    tgt_off = np.ascontiguousarray(tgt_off, dtype=np.int64)
+    S = src_off.shape[0] - 1
+    if tgt_off.shape[0] - 1 != S:
+        raise ValueError("src_off and tgt_off must describe the same number of problems")
+    if S and (src_off[-1] > src.shape[0] or tgt_off[-1] > tgt.shape[0]):
+        raise ValueError("offsets run past the end of the point buffers")
+    init_T = np.ascontiguousarray(init_T, dtype=np.float64).reshape(S, 4, 4)
+    out_T = np.empty((S, 4, 4), dtype=np.float64)
+    out_err = np.empty(S, dtype=np.float64)
+    out_it = np.empty(S, dtype=np.int32)
+    corr = np.empty(int(src_off[-1]) if S else 0, dtype=np.int32) if return_correspondences else None
+    flags = _lib.ICP_NORMALIZE_ERROR if normalize_error else 0
+    check(lib().lslam_icp_batch(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), src.shape[1], ptr(init_T), S,
+                                float(epsilon), float(stopping_thresh), int(max_iters), flags,
+                                ptr(out_T), ptr(out_err), ptr(out_it), ptr(corr), int(device)))
+    return IcpBatchResult(out_T, out_err, out_it, corr)
+
+
+def icp_batch_dev(d_src, d_src_off, d_tgt, d_tgt_off, dim, d_init_T, S, max_src_n, max_tgt_n,
+                  d_out_T, d_out_err, d_out_iters, d_out_corr=None, epsilon=0.01, max_iters=2000,
+                  stopping_thresh=0.0001, normalize_error=False, stream=0) -> None:
+    """Same on DEVICE pointers (ints, e.g. torch.Tensor.data_ptr()); enqueues and returns."""
+    flags = _lib.ICP_NORMALIZE_ERROR if normalize_error else 0
+    check(lib().lslam_icp_batch_dev(d_src, d_src_off, d_tgt, d_tgt_off, int(dim), d_init_T, int(S),
+                                    int(max_src_n), int(max_tgt_n), float(epsilon), float(stopping_thresh),
+                                    int(max_iters), flags, d_out_T, d_out_err, d_out_iters,
+                                    d_out_corr or None, stream or None))
+
+
+def icp_large_dev(d_src, n, d_tgt, m, dim, init_T, epsilon=0.01, max_iters=2000, stopping_thresh=0.0001,
+                  normalize_error=False, d_out_corr=None, poll_every=8, stream=0):
+    """run_icp on one large cloud pair resident on the device; returns (T, error, iterations)."""
+    init_T = np.ascontiguousarray(init_T, dtype=np.float64).reshape(4, 4)
+    out_T = np.empty((4, 4), dtype=np.float64)
+    out_err = np.empty(1, dtype=np.float64)
+    out_it = np.empty(1, dtype=np.int32)
+    flags = _lib.ICP_NORMALIZE_ERROR if normalize_error else 0
+    check(lib().lslam_icp_large_dev(d_src, int(n), d_tgt, int(m), int(dim), ptr(init_T), float(epsilon),
+                                    float(stopping_thresh), int(max_iters), flags, int(poll_every),
+                                    ptr(out_T), ptr(out_err), ptr(out_it), d_out_corr or None, stream or None))
+    return out_T, float(out_err[0]), int(out_it[0])
+
+
+def nn_dev(d_src, n, d_tgt, m, dim, T, d_out_idx, d_out_d2=None, stream=0) -> None:
+    T = None if T is None else np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
+    check(lib().lslam_nn_dev(d_src, int(n), d_tgt, int(m), int(dim), ptr(T), d_out_idx, d_out_d2 or None,
+                             stream or None))

@@ -1,0 +1,582 @@
+// lslam_api.hip — the C ABI declared in include/lslam.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "lslam_host.h"
+#include "lslam_kernels.h"
+
+namespace lslam {
+
+// ---- error string ---------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+void clear_error() { g_err[0] = 0; }
+
+// ---- scratch arena --------------------------------------------------------------------------------
+int Arena::reserve(int device, size_t bytes) {
+  used_ = 0;
+  if (device == device_ && bytes <= cap_) return LSLAM_OK;
+  if (base_) { (void)hipFree(base_); base_ = nullptr; cap_ = 0; }
+  size_t want = bytes + (bytes >> 2) + (1u << 20);          // head-room: avoid re-growing every call
+  LSLAM_HIP_TRY(hipMalloc(&base_, want));
+  cap_ = want;
+  device_ = device;
+  return LSLAM_OK;
+}
+void* Arena::carve(size_t bytes) {
+  void* p = static_cast<char*>(base_) + used_;
+  used_ += align(bytes);
+  return used_ <= cap_ ? p : nullptr;
+}
+Arena& thread_arena() {
+  static thread_local Arena a;
+  return a;
+}
+int thread_stream(hipStream_t* out) {
+  static thread_local hipStream_t s = nullptr;
+  static thread_local int dev = -1;
+  int cur = 0;
+  LSLAM_HIP_TRY(hipGetDevice(&cur));
+  if (!s || dev != cur) {
+    LSLAM_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    dev = cur;
+  }
+  *out = s;
+  return LSLAM_OK;
+}
+
+static int use_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(LSLAM_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(LSLAM_ERR_BAD_ARG, "device %d out of range [0,%d)", device, n);
+  LSLAM_HIP_TRY(hipSetDevice(device));
+  return LSLAM_OK;
+}
+
+static bool all_finite(const float* v, int64_t count) {
+  // a float is non-finite iff its exponent bits are all ones
+  const uint32_t* u = reinterpret_cast<const uint32_t*>(v);
+  uint32_t bad = 0;
+  for (int64_t i = 0; i < count; ++i) bad |= ((u[i] & 0x7f800000u) == 0x7f800000u);
+  return bad == 0;
+}
+
+static int check_offsets(const int64_t* off, int32_t S, const char* what, int64_t* max_len, int64_t* total) {
+  int64_t mx = 0;
+  if (off[0] < 0) return fail(LSLAM_ERR_BAD_ARG, "%s[0] is negative", what);
+  for (int32_t s = 0; s < S; ++s) {
+    const int64_t len = off[s + 1] - off[s];
+    if (len < 0) return fail(LSLAM_ERR_BAD_ARG, "%s is not monotone at %d", what, s);
+    if (len > 0x7fffffff) return fail(LSLAM_ERR_BAD_ARG, "%s: problem %d has more than 2^31 points", what, s);
+    if (len > mx) mx = len;
+  }
+  *max_len = mx;
+  *total = off[S];
+  return LSLAM_OK;
+}
+
+static IcpBatchTuning tuning_from_env() {
+  IcpBatchTuning t;
+  if (const char* e = getenv("LSLAM_ICP_POINTS_PER_LANE")) t.points_per_lane = atoi(e);
+  if (const char* e = getenv("LSLAM_ICP_THREADS")) t.threads = atoi(e);
+  if (const char* e = getenv("LSLAM_ICP_TILE_POINTS")) t.tile_points = atoi(e);
+  return t;
+}
+
+}  // namespace lslam
+
+using namespace lslam;
+
+extern "C" {
+
+int lslam_abi_version(void) { return LSLAM_ABI_VERSION; }
+const char* lslam_last_error(void) { return g_err; }
+
+int lslam_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int lslam_set_device(int device) {
+  clear_error();
+  return use_device(device);
+}
+
+// ---------------------------------------------------------------------------------------------------
+int lslam_icp_batch_dev(const float* d_src, const int64_t* d_src_off, const float* d_tgt,
+                        const int64_t* d_tgt_off, int dim, const double* d_init_T, int32_t S,
+                        int64_t max_src_n, int64_t max_tgt_n, double epsilon, double stopping_thresh,
+                        int32_t max_iters, uint32_t flags, double* d_out_T, double* d_out_err,
+                        int32_t* d_out_iters, int32_t* d_out_corr, void* stream) {
+  clear_error();
+  if (dim != 2 && dim != 3) return fail(LSLAM_ERR_BAD_ARG, "dim must be 2 or 3, got %d", dim);
+  if (S < 0) return fail(LSLAM_ERR_BAD_ARG, "negative batch size");
+  if (S == 0) return LSLAM_OK;
+  if (!d_src || !d_src_off || !d_tgt || !d_tgt_off || !d_init_T || !d_out_T || !d_out_err || !d_out_iters)
+    return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (max_src_n < 0 || max_tgt_n <= 0) return fail(LSLAM_ERR_BAD_ARG, "max_src_n/max_tgt_n must be positive");
+  IcpBatchArgs a{};
+  a.src = d_src; a.src_off = d_src_off; a.tgt = d_tgt; a.tgt_off = d_tgt_off;
+  a.init_T = d_init_T; a.out_T = d_out_T; a.out_err = d_out_err; a.out_iters = d_out_iters;
+  a.out_corr = d_out_corr;
+  a.epsilon = epsilon; a.stopping_thresh = stopping_thresh; a.max_iters = max_iters; a.flags = flags;
+  LSLAM_HIP_TRY(launch_icp_batch(a, dim, S, max_src_n, max_tgt_n, tuning_from_env(), static_cast<hipStream_t>(stream)));
+  return LSLAM_OK;
+}
+
+int lslam_icp_batch(const float* src, const int64_t* src_off, const float* tgt, const int64_t* tgt_off,
+                    int dim, const double* init_T, int32_t S, double epsilon, double stopping_thresh,
+                    int32_t max_iters, uint32_t flags, double* out_T, double* out_err,
+                    int32_t* out_iters, int32_t* out_corr, int device) {
+  clear_error();
+  if (dim != 2 && dim != 3) return fail(LSLAM_ERR_BAD_ARG, "dim must be 2 or 3, got %d", dim);
+  if (S < 0) return fail(LSLAM_ERR_BAD_ARG, "negative batch size");
+  if (S == 0) return LSLAM_OK;
+  if (!src || !src_off || !tgt || !tgt_off || !init_T || !out_T || !out_err || !out_iters)
+    return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  int64_t max_n = 0, max_m = 0, tot_n = 0, tot_m = 0;
+  int rc;
+  if ((rc = check_offsets(src_off, S, "src_off", &max_n, &tot_n)) != LSLAM_OK) return rc;
+  if ((rc = check_offsets(tgt_off, S, "tgt_off", &max_m, &tot_m)) != LSLAM_OK) return rc;
+  for (int32_t s = 0; s < S; ++s)
+    if (tgt_off[s + 1] == tgt_off[s]) return fail(LSLAM_ERR_EMPTY_TARGET, "problem %d has an empty target cloud", s);
+  if (!all_finite(src + dim * src_off[0], dim * (tot_n - src_off[0])) ||
+      !all_finite(tgt + dim * tgt_off[0], dim * (tot_m - tgt_off[0])))
+    return fail(LSLAM_ERR_NONFINITE, "point clouds must be finite (NaN or Inf found)");
+  if ((rc = use_device(device)) != LSLAM_OK) return rc;
+
+  const bool shared = (src == tgt);                       // scan sequence: upload the scans once
+  const int64_t up_src = shared ? (tot_n > tot_m ? tot_n : tot_m) : tot_n;
+  const size_t b_src = sizeof(float) * dim * (size_t)up_src;
+  const size_t b_tgt = shared ? 0 : sizeof(float) * dim * (size_t)tot_m;
+  const size_t b_off = sizeof(int64_t) * ((size_t)S + 1);
+  const size_t b_T = sizeof(double) * 16 * (size_t)S;
+  const size_t b_corr = out_corr ? sizeof(int32_t) * (size_t)tot_n : 0;
+  Arena& ar = thread_arena();
+  const size_t total = Arena::align(b_src) + Arena::align(b_tgt) + 2 * Arena::align(b_off) + 2 * Arena::align(b_T) +
+                       Arena::align(sizeof(double) * S) + Arena::align(sizeof(int32_t) * S) + Arena::align(b_corr);
+  if ((rc = ar.reserve(device, total)) != LSLAM_OK) return rc;
+  float* d_src = static_cast<float*>(ar.carve(b_src));
+  float* d_tgt = shared ? d_src : static_cast<float*>(ar.carve(b_tgt));
+  int64_t* d_so = static_cast<int64_t*>(ar.carve(b_off));
+  int64_t* d_to = static_cast<int64_t*>(ar.carve(b_off));
+  double* d_iT = static_cast<double*>(ar.carve(b_T));
+  double* d_oT = static_cast<double*>(ar.carve(b_T));
+  double* d_err = static_cast<double*>(ar.carve(sizeof(double) * S));
+  int32_t* d_it = static_cast<int32_t*>(ar.carve(sizeof(int32_t) * S));
+  int32_t* d_corr = out_corr ? static_cast<int32_t*>(ar.carve(b_corr)) : nullptr;
+
+  hipStream_t st;
+  if ((rc = thread_stream(&st)) != LSLAM_OK) return rc;
+  LSLAM_HIP_TRY(hipMemcpyAsync(d_src, src, b_src, hipMemcpyHostToDevice, st));
+  if (!shared) LSLAM_HIP_TRY(hipMemcpyAsync(d_tgt, tgt, b_tgt, hipMemcpyHostToDevice, st));
+  LSLAM_HIP_TRY(hipMemcpyAsync(d_so, src_off, b_off, hipMemcpyHostToDevice, st));
+  LSLAM_HIP_TRY(hipMemcpyAsync(d_to, tgt_off, b_off, hipMemcpyHostToDevice, st));
+  LSLAM_HIP_TRY(hipMemcpyAsync(d_iT, init_T, b_T, hipMemcpyHostToDevice, st));
+  rc = lslam_icp_batch_dev(d_src, d_so, d_tgt, d_to, dim, d_iT, S, max_n, max_m, epsilon, stopping_thresh,
+                           max_iters, flags, d_oT, d_err, d_it, d_corr, st);
+  if (rc != LSLAM_OK) return rc;
+  LSLAM_HIP_TRY(hipMemcpyAsync(out_T, d_oT, b_T, hipMemcpyDeviceToHost, st));
+  LSLAM_HIP_TRY(hipMemcpyAsync(out_err, d_err, sizeof(double) * S, hipMemcpyDeviceToHost, st));
+  LSLAM_HIP_TRY(hipMemcpyAsync(out_iters, d_it, sizeof(int32_t) * S, hipMemcpyDeviceToHost, st));
+  if (out_corr) LSLAM_HIP_TRY(hipMemcpyAsync(out_corr, d_corr, b_corr, hipMemcpyDeviceToHost, st));
+  LSLAM_HIP_TRY(hipStreamSynchronize(st));
+  return LSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per-(thread, device) workspace of the large path: keys, partial rows, state, pinned flag mirror.
+extern "C++" {
+namespace {
+struct LargeWs {
+  int device = -1;
+  unsigned long long* keys = nullptr; int64_t keys_cap = 0;
+  double* partials = nullptr;
+  LargeState* state = nullptr;
+  LargeState* h_state = nullptr;       // pinned
+  int ensure(int dev, int64_t n) {
+    if (dev != device) { release(); device = dev; }
+    if (!partials) {
+      LSLAM_HIP_TRY(hipMalloc(&partials, sizeof(double) * (size_t)kMomMaxBlocks * 32));
+      LSLAM_HIP_TRY(hipMalloc(&state, sizeof(LargeState)));
+      LSLAM_HIP_TRY(hipHostMalloc(&h_state, sizeof(LargeState)));
+    }
+    if (n > keys_cap) {
+      if (keys) (void)hipFree(keys);
+      keys = nullptr; keys_cap = 0;
+      LSLAM_HIP_TRY(hipMalloc(&keys, sizeof(unsigned long long) * (size_t)n));
+      keys_cap = n;
+    }
+    return LSLAM_OK;
+  }
+  void release() {
+    if (keys) (void)hipFree(keys);
+    if (partials) (void)hipFree(partials);
+    if (state) (void)hipFree(state);
+    if (h_state) (void)hipHostFree(h_state);
+    keys = nullptr; partials = nullptr; state = nullptr; h_state = nullptr; keys_cap = 0;
+  }
+};
+LargeWs& large_ws() { static thread_local LargeWs w; return w; }
+}  // namespace
+}  // extern "C++"
+
+int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64_t m, int dim,
+                        const double* init_T, double epsilon, double stopping_thresh, int32_t max_iters,
+                        uint32_t flags, int32_t poll_every, double* out_T, double* out_err,
+                        int32_t* out_iters, int32_t* d_out_corr, void* stream) {
+  clear_error();
+  if (dim != 2 && dim != 3) return fail(LSLAM_ERR_BAD_ARG, "dim must be 2 or 3, got %d", dim);
+  if (!d_src || !d_tgt || !init_T || !out_T || !out_err || !out_iters) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (n <= 0) return fail(LSLAM_ERR_BAD_ARG, "empty source cloud");
+  if (m <= 0) return fail(LSLAM_ERR_EMPTY_TARGET, "empty target cloud");
+  if (n > 0x7fffffff || m > 0x7fffffff) return fail(LSLAM_ERR_BAD_ARG, "clouds above 2^31 points are not supported");
+  if (poll_every <= 0) poll_every = 8;
+  int dev = 0;
+  LSLAM_HIP_TRY(hipGetDevice(&dev));
+  LargeWs& ws = large_ws();
+  int rc = ws.ensure(dev, n);
+  if (rc != LSLAM_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+
+  LargeState* hs = ws.h_state;
+  memcpy(hs->T, init_T, sizeof(double) * 16);
+  hs->err = 0.0;
+  stop_init(hs->stop);
+  hs->done = 0;
+  LSLAM_HIP_TRY(hipMemcpyAsync(ws.state, hs, sizeof(LargeState), hipMemcpyHostToDevice, st));
+  LSLAM_HIP_TRY(launch_keys_init(ws.keys, n, st));
+
+  NnArgs na{};
+  na.src = d_src; na.n = n; na.tgt = d_tgt; na.m = m; na.keys = ws.keys; na.state = ws.state;
+  MomArgs ma{};
+  ma.src = d_src; ma.n = n; ma.tgt = d_tgt; ma.keys = ws.keys; ma.state = ws.state; ma.partials = ws.partials;
+  ma.out_corr = d_out_corr; ma.flags = flags;
+  const int rows = moments_rows(n);
+  SolveArgs sa{};
+  sa.state = ws.state; sa.partials = ws.partials; sa.rows = rows; sa.flags = flags;
+  sa.epsilon = epsilon; sa.stopping_thresh = stopping_thresh; sa.max_iters = max_iters;
+
+  // at most max_iters + 1 iterations run (icp.py:174); enqueue in groups and poll the flag between
+  const int64_t cap = (int64_t)max_iters + 1;
+  int64_t launched = 0;
+  for (;;) {
+    for (int k = 0; k < poll_every && launched < cap; ++k, ++launched) {
+      LSLAM_HIP_TRY(launch_nn(na, dim, st));
+      LSLAM_HIP_TRY(launch_moments(ma, dim, rows, st));
+      LSLAM_HIP_TRY(launch_solve(sa, dim, st));
+    }
+    LSLAM_HIP_TRY(hipMemcpyAsync(hs, ws.state, sizeof(LargeState), hipMemcpyDeviceToHost, st));
+    LSLAM_HIP_TRY(hipStreamSynchronize(st));
+    if (hs->done || launched >= cap) break;
+  }
+  memcpy(out_T, hs->T, sizeof(double) * 16);
+  *out_err = hs->err;
+  *out_iters = hs->stop.executed;
+  return LSLAM_OK;
+}
+
+int lslam_nn_dev(const float* d_src, int64_t n, const float* d_tgt, int64_t m, int dim, const double* T,
+                 int32_t* d_out_idx, float* d_out_d2, void* stream) {
+  clear_error();
+  if (dim != 2 && dim != 3) return fail(LSLAM_ERR_BAD_ARG, "dim must be 2 or 3, got %d", dim);
+  if (n < 0) return fail(LSLAM_ERR_BAD_ARG, "negative source size");
+  if (n == 0) return LSLAM_OK;
+  if (!d_src || !d_tgt || !d_out_idx) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (m <= 0) return fail(LSLAM_ERR_EMPTY_TARGET, "empty target cloud");
+  if (n > 0x7fffffff || m > 0x7fffffff) return fail(LSLAM_ERR_BAD_ARG, "clouds above 2^31 points are not supported");
+  int dev = 0;
+  LSLAM_HIP_TRY(hipGetDevice(&dev));
+  LargeWs& ws = large_ws();
+  int rc = ws.ensure(dev, n);
+  if (rc != LSLAM_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  NnArgs na{};
+  na.src = d_src; na.n = n; na.tgt = d_tgt; na.m = m; na.keys = ws.keys; na.state = nullptr;
+  static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  memcpy(na.T, T ? T : I4, sizeof(double) * 16);
+  LSLAM_HIP_TRY(launch_keys_init(ws.keys, n, st));
+  LSLAM_HIP_TRY(launch_nn(na, dim, st));
+  LSLAM_HIP_TRY(launch_nn_finalize(ws.keys, n, d_out_idx, d_out_d2, st));
+  return LSLAM_OK;
+}
+
+// host-pointer wrappers of the two entry points above
+static int upload_pair(const float* src, int64_t n, const float* tgt, int64_t m, int dim, int device,
+                       size_t extra, float** d_src, float** d_tgt, void** d_extra, hipStream_t* st) {
+  if (!all_finite(src, dim * n) || !all_finite(tgt, dim * m))
+    return fail(LSLAM_ERR_NONFINITE, "point clouds must be finite (NaN or Inf found)");
+  int rc;
+  if ((rc = use_device(device)) != LSLAM_OK) return rc;
+  Arena& ar = thread_arena();
+  const size_t bs = sizeof(float) * dim * (size_t)n, bt = sizeof(float) * dim * (size_t)m;
+  if ((rc = ar.reserve(device, Arena::align(bs) + Arena::align(bt) + Arena::align(extra))) != LSLAM_OK) return rc;
+  *d_src = static_cast<float*>(ar.carve(bs));
+  *d_tgt = static_cast<float*>(ar.carve(bt));
+  *d_extra = extra ? ar.carve(extra) : nullptr;
+  if ((rc = thread_stream(st)) != LSLAM_OK) return rc;
+  LSLAM_HIP_TRY(hipMemcpyAsync(*d_src, src, bs, hipMemcpyHostToDevice, *st));
+  LSLAM_HIP_TRY(hipMemcpyAsync(*d_tgt, tgt, bt, hipMemcpyHostToDevice, *st));
+  return LSLAM_OK;
+}
+
+int lslam_icp_large(const float* src, int64_t n, const float* tgt, int64_t m, int dim, const double* init_T,
+                    double epsilon, double stopping_thresh, int32_t max_iters, uint32_t flags,
+                    double* out_T, double* out_err, int32_t* out_iters, int32_t* out_corr, int device) {
+  clear_error();
+  if (dim != 2 && dim != 3) return fail(LSLAM_ERR_BAD_ARG, "dim must be 2 or 3, got %d", dim);
+  if (!src || !tgt) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (n <= 0) return fail(LSLAM_ERR_BAD_ARG, "empty source cloud");
+  if (m <= 0) return fail(LSLAM_ERR_EMPTY_TARGET, "empty target cloud");
+  float *d_src, *d_tgt; void* d_corr; hipStream_t st;
+  int rc = upload_pair(src, n, tgt, m, dim, device, out_corr ? sizeof(int32_t) * (size_t)n : 0, &d_src, &d_tgt, &d_corr, &st);
+  if (rc != LSLAM_OK) return rc;
+  rc = lslam_icp_large_dev(d_src, n, d_tgt, m, dim, init_T, epsilon, stopping_thresh, max_iters, flags, 8,
+                           out_T, out_err, out_iters, static_cast<int32_t*>(d_corr), st);
+  if (rc != LSLAM_OK) return rc;
+  if (out_corr) {
+    LSLAM_HIP_TRY(hipMemcpyAsync(out_corr, d_corr, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+    LSLAM_HIP_TRY(hipStreamSynchronize(st));
+  }
+  return LSLAM_OK;
+}
+
+int lslam_nn(const float* src, int64_t n, const float* tgt, int64_t m, int dim, const double* T,
+             int32_t* out_idx, float* out_d2, int device) {
+  clear_error();
+  if (dim != 2 && dim != 3) return fail(LSLAM_ERR_BAD_ARG, "dim must be 2 or 3, got %d", dim);
+  if (n < 0) return fail(LSLAM_ERR_BAD_ARG, "negative source size");
+  if (n == 0) return LSLAM_OK;
+  if (!src || !tgt || !out_idx) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (m <= 0) return fail(LSLAM_ERR_EMPTY_TARGET, "empty target cloud");
+  float *d_src, *d_tgt; void* d_out; hipStream_t st;
+  const size_t bi = Arena::align(sizeof(int32_t) * (size_t)n);
+  int rc = upload_pair(src, n, tgt, m, dim, device, bi + sizeof(float) * (size_t)n, &d_src, &d_tgt, &d_out, &st);
+  if (rc != LSLAM_OK) return rc;
+  int32_t* d_idx = static_cast<int32_t*>(d_out);
+  float* d_d2 = reinterpret_cast<float*>(static_cast<char*>(d_out) + bi);
+  rc = lslam_nn_dev(d_src, n, d_tgt, m, dim, T, d_idx, out_d2 ? d_d2 : nullptr, st);
+  if (rc != LSLAM_OK) return rc;
+  LSLAM_HIP_TRY(hipMemcpyAsync(out_idx, d_idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+  if (out_d2) LSLAM_HIP_TRY(hipMemcpyAsync(out_d2, d_d2, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+  LSLAM_HIP_TRY(hipStreamSynchronize(st));
+  return LSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+static int pair_op(const double* p, int64_t ps, const double* q, int64_t qs, int64_t n, int32_t cols,
+                   int32_t normalize, double* out_T, double* out_err, int device) {
+  int rc;
+  if ((rc = use_device(device)) != LSLAM_OK) return rc;
+  Arena& ar = thread_arena();
+  const size_t bp = sizeof(double) * (size_t)(n > 0 ? (n - 1) * ps + cols : 0);
+  const size_t bq = sizeof(double) * (size_t)(n > 0 ? (n - 1) * qs + cols : 0);
+  if ((rc = ar.reserve(device, Arena::align(bp) + Arena::align(bq) + 512)) != LSLAM_OK) return rc;
+  double* dp = static_cast<double*>(ar.carve(bp));
+  double* dq = static_cast<double*>(ar.carve(bq));
+  double* dT = static_cast<double*>(ar.carve(sizeof(double) * 16));
+  double* de = static_cast<double*>(ar.carve(sizeof(double)));
+  hipStream_t st;
+  if ((rc = thread_stream(&st)) != LSLAM_OK) return rc;
+  if (bp) LSLAM_HIP_TRY(hipMemcpyAsync(dp, p, bp, hipMemcpyHostToDevice, st));
+  if (bq) LSLAM_HIP_TRY(hipMemcpyAsync(dq, q, bq, hipMemcpyHostToDevice, st));
+  PairOpArgs a{};
+  a.p = dp; a.p_stride = ps; a.q = dq; a.q_stride = qs; a.n = n; a.cols = cols; a.normalize = normalize;
+  a.out_T = out_T ? dT : nullptr; a.out_err = out_err ? de : nullptr;
+  LSLAM_HIP_TRY(launch_pair_op(a, st));
+  if (out_T) LSLAM_HIP_TRY(hipMemcpyAsync(out_T, dT, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+  if (out_err) LSLAM_HIP_TRY(hipMemcpyAsync(out_err, de, sizeof(double), hipMemcpyDeviceToHost, st));
+  LSLAM_HIP_TRY(hipStreamSynchronize(st));
+  return LSLAM_OK;
+}
+
+int lslam_kabsch(const double* p, int64_t p_stride, const double* q, int64_t q_stride, int64_t n,
+                 double* out_T, int device) {
+  clear_error();
+  if (!p || !q || !out_T) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (n < 0 || p_stride < 3 || q_stride < 3) return fail(LSLAM_ERR_BAD_ARG, "need n >= 0 and row strides >= 3");
+  return pair_op(p, p_stride, q, q_stride, n, 3, 0, out_T, nullptr, device);
+}
+
+int lslam_sq_error(const double* p, const double* q, int64_t n, int32_t cols, int32_t normalize,
+                   double* out_err, int device) {
+  clear_error();
+  if (!p || !q || !out_err) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (n < 0 || cols < 1 || cols > 3) return fail(LSLAM_ERR_BAD_ARG, "need n >= 0 and 1 <= cols <= 3");
+  return pair_op(p, cols, q, cols, n, cols, normalize, nullptr, out_err, device);
+}
+
+// ---------------------------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+struct Ogm {
+  OgmGrid g{};
+  int device = 0;
+  int parity = 0;
+  hipStream_t stream = nullptr;
+  double* d_scan = nullptr; int64_t scan_cap = 0;     // points
+  uint8_t* d_bin = nullptr;
+};
+int ogm_scan_buffer(Ogm* o, int64_t points) {
+  if (points <= o->scan_cap) return LSLAM_OK;
+  if (o->d_scan) (void)hipFree(o->d_scan);
+  o->d_scan = nullptr; o->scan_cap = 0;
+  const int64_t want = points + points / 4 + 1024;
+  LSLAM_HIP_TRY(hipMalloc(&o->d_scan, sizeof(double) * 2 * (size_t)want));
+  o->scan_cap = want;
+  return LSLAM_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int lslam_ogm_create(double res, double world_min_x, double world_min_y, int32_t width, int32_t height,
+                     double logodds_step, double logodds_clip, int device, void** out_handle) {
+  clear_error();
+  if (!out_handle) return fail(LSLAM_ERR_BAD_ARG, "null handle pointer");
+  *out_handle = nullptr;
+  if (!(res > 0.0) || width <= 0 || height <= 0) return fail(LSLAM_ERR_BAD_ARG, "need res > 0 and positive grid dimensions");
+  int rc;
+  if ((rc = use_device(device)) != LSLAM_OK) return rc;
+  Ogm* o = new (std::nothrow) Ogm();
+  if (!o) return fail(LSLAM_ERR_BAD_ARG, "out of host memory");
+  o->device = device;
+  o->g.width = width; o->g.height = height; o->g.res = res; o->g.min_x = world_min_x; o->g.min_y = world_min_y;
+  o->g.step = logodds_step; o->g.clip = logodds_clip;
+  const size_t cells = (size_t)width * height;
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipMalloc(&o->g.logodds, sizeof(float) * cells)) != hipSuccess ||
+      (e = hipMalloc(&o->g.counts, sizeof(int32_t) * cells)) != hipSuccess ||
+      (e = hipMalloc(&o->g.bbox, sizeof(int32_t) * 8)) != hipSuccess ||
+      (e = hipMalloc(&o->d_bin, cells)) != hipSuccess ||
+      (e = launch_ogm_init(o->g, o->stream)) != hipSuccess ||
+      (e = hipStreamSynchronize(o->stream)) != hipSuccess) {
+    lslam_ogm_destroy(o);
+    return fail(LSLAM_ERR_HIP, "occupancy grid allocation failed: %s", hipGetErrorString(e));
+  }
+  *out_handle = o;
+  return LSLAM_OK;
+}
+
+int lslam_ogm_destroy(void* handle) {
+  if (!handle) return LSLAM_OK;
+  Ogm* o = static_cast<Ogm*>(handle);
+  (void)hipSetDevice(o->device);
+  if (o->stream) (void)hipStreamSynchronize(o->stream);
+  if (o->g.logodds) (void)hipFree(o->g.logodds);
+  if (o->g.counts) (void)hipFree(o->g.counts);
+  if (o->g.bbox) (void)hipFree(o->g.bbox);
+  if (o->d_scan) (void)hipFree(o->d_scan);
+  if (o->d_bin) (void)hipFree(o->d_bin);
+  if (o->stream) (void)hipStreamDestroy(o->stream);
+  delete o;
+  return LSLAM_OK;
+}
+
+int lslam_ogm_set_params(void* handle, double logodds_step, double logodds_clip) {
+  clear_error();
+  if (!handle) return fail(LSLAM_ERR_BAD_ARG, "null handle");
+  Ogm* o = static_cast<Ogm*>(handle);
+  o->g.step = logodds_step;
+  o->g.clip = logodds_clip;
+  return LSLAM_OK;
+}
+
+static int ogm_enqueue_scan(Ogm* o, const double* pose, const double* d_scan, int32_t n, bool apply) {
+  OgmScan sc{};
+  sc.scan_xy = d_scan; sc.n = n;
+  sc.x = pose[0]; sc.y = pose[1]; sc.c = cos(pose[2]); sc.s = sin(pose[2]);
+  sc.parity = o->parity;
+  LSLAM_HIP_TRY(launch_ogm_raycast(o->g, sc, o->stream));
+  if (apply) LSLAM_HIP_TRY(launch_ogm_apply(o->g, o->parity, o->stream));
+  o->parity ^= 1;
+  return LSLAM_OK;
+}
+
+int lslam_ogm_update(void* handle, const double* poses, const double* scans_xy, const int64_t* scan_off, int32_t K) {
+  clear_error();
+  if (!handle || !poses || !scan_off) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (K < 0) return fail(LSLAM_ERR_BAD_ARG, "negative scan count");
+  Ogm* o = static_cast<Ogm*>(handle);
+  LSLAM_HIP_TRY(hipSetDevice(o->device));
+  for (int32_t k = 0; k < K; ++k)
+    if (scan_off[k + 1] < scan_off[k] || scan_off[k + 1] - scan_off[k] > 0x7fffffff)
+      return fail(LSLAM_ERR_BAD_ARG, "scan_off is not monotone at %d", k);
+  const int64_t first = scan_off[0], total = scan_off[K] - first;
+  int rc;
+  if ((rc = ogm_scan_buffer(o, total)) != LSLAM_OK) return rc;
+  if (total > 0) {
+    if (!scans_xy) return fail(LSLAM_ERR_BAD_ARG, "null scan pointer");
+    LSLAM_HIP_TRY(hipMemcpyAsync(o->d_scan, scans_xy + 2 * first, sizeof(double) * 2 * (size_t)total, hipMemcpyHostToDevice, o->stream));
+  }
+  for (int32_t k = 0; k < K; ++k) {
+    const int32_t n = (int32_t)(scan_off[k + 1] - scan_off[k]);
+    if ((rc = ogm_enqueue_scan(o, poses + 3 * (size_t)k, o->d_scan + 2 * (scan_off[k] - first), n, true)) != LSLAM_OK) return rc;
+  }
+  LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+  return LSLAM_OK;
+}
+
+int lslam_ogm_scan_counts(void* handle, const double* pose, const double* scan_xy, int32_t n, int32_t* out_counts) {
+  clear_error();
+  if (!handle || !pose || !out_counts || (n > 0 && !scan_xy)) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (n < 0) return fail(LSLAM_ERR_BAD_ARG, "negative ray count");
+  Ogm* o = static_cast<Ogm*>(handle);
+  LSLAM_HIP_TRY(hipSetDevice(o->device));
+  int rc;
+  if ((rc = ogm_scan_buffer(o, n)) != LSLAM_OK) return rc;
+  if (n > 0) LSLAM_HIP_TRY(hipMemcpyAsync(o->d_scan, scan_xy, sizeof(double) * 2 * (size_t)n, hipMemcpyHostToDevice, o->stream));
+  const int parity = o->parity;
+  if ((rc = ogm_enqueue_scan(o, pose, o->d_scan, n, false)) != LSLAM_OK) return rc;
+  LSLAM_HIP_TRY(hipMemcpyAsync(out_counts, o->g.counts, sizeof(int32_t) * (size_t)o->g.width * o->g.height, hipMemcpyDeviceToHost, o->stream));
+  LSLAM_HIP_TRY(launch_ogm_clear_counts(o->g, parity, o->stream));
+  LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+  return LSLAM_OK;
+}
+
+int lslam_ogm_read_logodds(void* handle, float* out) {
+  clear_error();
+  if (!handle || !out) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  Ogm* o = static_cast<Ogm*>(handle);
+  LSLAM_HIP_TRY(hipSetDevice(o->device));
+  LSLAM_HIP_TRY(hipMemcpyAsync(out, o->g.logodds, sizeof(float) * (size_t)o->g.width * o->g.height, hipMemcpyDeviceToHost, o->stream));
+  LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+  return LSLAM_OK;
+}
+
+int lslam_ogm_write_logodds(void* handle, const float* in) {
+  clear_error();
+  if (!handle || !in) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  Ogm* o = static_cast<Ogm*>(handle);
+  LSLAM_HIP_TRY(hipSetDevice(o->device));
+  LSLAM_HIP_TRY(hipMemcpyAsync(o->g.logodds, in, sizeof(float) * (size_t)o->g.width * o->g.height, hipMemcpyHostToDevice, o->stream));
+  LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+  return LSLAM_OK;
+}
+
+int lslam_ogm_binarize(void* handle, uint8_t* out) {
+  clear_error();
+  if (!handle || !out) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  Ogm* o = static_cast<Ogm*>(handle);
+  LSLAM_HIP_TRY(hipSetDevice(o->device));
+  LSLAM_HIP_TRY(launch_ogm_binarize(o->g, o->d_bin, o->stream));
+  LSLAM_HIP_TRY(hipMemcpyAsync(out, o->d_bin, (size_t)o->g.width * o->g.height, hipMemcpyDeviceToHost, o->stream));
+  LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+  return LSLAM_OK;
+}
+
+}  // extern "C"

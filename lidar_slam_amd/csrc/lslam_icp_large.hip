@@ -1,0 +1,331 @@
+// lslam_icp_large.hip — ICP on ONE large cloud pair with the whole chip on it (config "100k × 100k").
+//
+// Per iteration (modules/icp.py:100-121), three launches on one stream, no host round trip:
+//   nn_tiled_kernel   grid = (source blocks) × (target splits).  A workgroup owns 256·P source points
+//                     in registers (transformed on load: icp.py:116 fused) and sweeps its share of the
+//                     target through LDS tiles with wave-uniform ds_read_b128 — the same
+//                     distance / v_min3 / (min, chunk) inner loop as the batched kernel.  Per source
+//                     the partial result is merged with atomicMin on a 64-bit key
+//                     (float bits of d² << 32 | index): exact argmin, lowest index on ties.
+//   moments_kernel    gathers the matched targets, accumulates the float64 moments per workgroup,
+//                     resets the keys for the next iteration, optionally writes correspondences.
+//   solve_kernel      one wave: fixed-order sum of the partial rows → Kabsch solve → stop rules →
+//                     new T and the `done` flag in device memory.
+// Every kernel returns at once when `done` is set, so the host may enqueue iterations ahead and
+// poll the flag only now and then.
+#include <hip/hip_runtime.h>
+
+#include "lslam_device.h"
+#include "lslam_kernels.h"
+
+namespace lslam {
+
+constexpr unsigned long long kKeyInit = ~0ull;
+
+template <int DIM, int P>
+__global__ void __launch_bounds__(kNnThreads)
+nn_tiled_kernel(NnArgs a) {
+  constexpr int CHUNK = IcpChunk<DIM>::value;
+  using TP = typename std::conditional<DIM == 2, float2, float4>::type;
+  extern __shared__ __align__(16) unsigned char smem[];
+  TP* tile = reinterpret_cast<TP*>(smem);
+
+  if (a.state && a.state->done) return;
+  const int tid = threadIdx.x;
+
+  double T[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) T[r][c] = a.state ? a.state->T[4 * r + c] : a.T[4 * r + c];
+
+  // ---- my source points ----------------------------------------------------------------------
+  const int64_t base = (int64_t)blockIdx.x * (kNnThreads * P);
+  float s[P][DIM];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int64_t i = base + (int64_t)p * kNnThreads + tid;
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (i < a.n) {
+      x = a.src[DIM * i]; y = a.src[DIM * i + 1];
+      if constexpr (DIM == 3) z = a.src[DIM * i + 2];
+    }
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) {
+      double v = T[r][0] * x + T[r][1] * y + T[r][3];
+      if constexpr (DIM == 3) v += T[r][2] * z;
+      s[p][r] = (float)v;
+    }
+  }
+
+  // ---- my share of the target ------------------------------------------------------------------
+  // splits are cut on CHUNK boundaries so that chunk ids are global
+  const int64_t chunks_total = (a.m + CHUNK - 1) / CHUNK;
+  const int64_t chunks_per_split = (chunks_total + gridDim.y - 1) / gridDim.y;
+  const int64_t c_begin = (int64_t)blockIdx.y * chunks_per_split;
+  const int64_t c_end = min(chunks_total, c_begin + chunks_per_split);
+
+  float best[P];
+  int bchunk[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) { best[p] = INFINITY; bchunk[p] = (int)c_begin; }
+
+  const int tile_chunks = a.tile_points / CHUNK;
+  for (int64_t c0 = c_begin; c0 < c_end; c0 += tile_chunks) {
+    const int nch = (int)min((int64_t)tile_chunks, c_end - c0);
+    const int64_t first = c0 * CHUNK;
+    __syncthreads();
+    for (int j = tid; j < nch * CHUNK; j += kNnThreads) {
+      const int64_t g = first + j;
+      TP v;
+      if constexpr (DIM == 2) {
+        v = make_float2(kFar, kFar);
+        if (g < a.m) v = *reinterpret_cast<const float2*>(a.tgt + 2 * g);
+      } else {
+        v = make_float4(kFar, kFar, kFar, 0.f);
+        if (g < a.m) { v.x = a.tgt[3 * g]; v.y = a.tgt[3 * g + 1]; v.z = a.tgt[3 * g + 2]; }
+      }
+      tile[j] = v;
+    }
+    __syncthreads();
+
+    if constexpr (DIM == 2) {
+      const float4* t4 = reinterpret_cast<const float4*>(tile);
+      for (int c = 0; c < nch; ++c) {
+        float4 v[CHUNK / 2];
+#pragma unroll
+        for (int k = 0; k < CHUNK / 2; ++k) v[k] = t4[c * (CHUNK / 2) + k];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          float mn = dist2(s[p][0], s[p][1], v[0].x, v[0].y);
+          mn = fminf(mn, dist2(s[p][0], s[p][1], v[0].z, v[0].w));
+#pragma unroll
+          for (int k = 1; k < CHUNK / 2; ++k) {
+            const float d0 = dist2(s[p][0], s[p][1], v[k].x, v[k].y);
+            const float d1 = dist2(s[p][0], s[p][1], v[k].z, v[k].w);
+            mn = fminf(fminf(d0, d1), mn);
+          }
+          const bool lt = mn < best[p];
+          bchunk[p] = lt ? (int)(c0 + c) : bchunk[p];
+          best[p] = lt ? mn : best[p];
+        }
+      }
+    } else {
+      for (int c = 0; c < nch; ++c) {
+        float4 v[CHUNK];
+#pragma unroll
+        for (int k = 0; k < CHUNK; ++k) v[k] = tile[c * CHUNK + k];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          float mn = dist2(s[p][0], s[p][1], s[p][2], v[0].x, v[0].y, v[0].z);
+#pragma unroll
+          for (int k = 1; k + 1 < CHUNK; k += 2) {
+            const float d0 = dist2(s[p][0], s[p][1], s[p][2], v[k].x, v[k].y, v[k].z);
+            const float d1 = dist2(s[p][0], s[p][1], s[p][2], v[k + 1].x, v[k + 1].y, v[k + 1].z);
+            mn = fminf(fminf(d0, d1), mn);
+          }
+          mn = fminf(mn, dist2(s[p][0], s[p][1], s[p][2], v[CHUNK - 1].x, v[CHUNK - 1].y, v[CHUNK - 1].z));
+          const bool lt = mn < best[p];
+          bchunk[p] = lt ? (int)(c0 + c) : bchunk[p];
+          best[p] = lt ? mn : best[p];
+        }
+      }
+    }
+  }
+  if (c_begin >= c_end) return;
+
+  // ---- fix-up from global memory (the winning chunk may have left LDS) + merge ------------------
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int64_t i = base + (int64_t)p * kNnThreads + tid;
+    if (i >= a.n) continue;
+    const int64_t j0 = (int64_t)bchunk[p] * CHUNK;
+    float bd = INFINITY;
+    int64_t bi = j0;
+#pragma unroll
+    for (int k = 0; k < CHUNK; ++k) {
+      const int64_t j = j0 + k;
+      const bool in = j < a.m;
+      const float bx = in ? a.tgt[DIM * j] : kFar;
+      const float by = in ? a.tgt[DIM * j + 1] : kFar;
+      float d;
+      if constexpr (DIM == 2) {
+        d = dist2(s[p][0], s[p][1], bx, by);
+      } else {
+        const float bz = in ? a.tgt[DIM * j + 2] : kFar;
+        d = dist2(s[p][0], s[p][1], s[p][2], bx, by, bz);
+      }
+      if (d < bd || k == 0) { bd = d; bi = j; }
+    }
+    const unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(uint32_t)bi;
+    atomicMin(a.keys + i, key);
+  }
+}
+
+// keys → (index, d²), keys reset.  Used by the NN-only entry point.
+__global__ void nn_finalize_kernel(unsigned long long* keys, int64_t n, int32_t* out_idx, float* out_d2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = keys[i];
+  if (out_idx) out_idx[i] = (int32_t)(uint32_t)(k & 0xffffffffull);
+  if (out_d2) out_d2[i] = __uint_as_float((uint32_t)(k >> 32));
+  keys[i] = kKeyInit;
+}
+
+__global__ void keys_init_kernel(unsigned long long* keys, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] = kKeyInit;
+}
+
+// ---- moments -------------------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(kMomThreads)
+moments_kernel(MomArgs a) {
+  constexpr int kAcc = AccLayout<DIM>::kTotal;
+  __shared__ double sh[kMomThreads / 64][kAcc];
+  if (a.state->done) return;
+  const bool box = (a.flags & kFlagNormalize) != 0;
+  double T[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) T[r][c] = a.state->T[4 * r + c];
+
+  PairAcc<DIM> acc;
+  acc.clear();
+  for (int64_t i = (int64_t)blockIdx.x * kMomThreads + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kMomThreads) {
+    const uint32_t j = (uint32_t)(a.keys[i] & 0xffffffffull);
+    a.keys[i] = kKeyInit;
+    if (a.out_corr) a.out_corr[i] = (int32_t)j;
+    double x = a.src[DIM * i], y = a.src[DIM * i + 1], z = 0.0;
+    if constexpr (DIM == 3) z = a.src[DIM * i + 2];
+    double p[DIM], q[DIM];
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) {
+      double v = T[r][0] * x + T[r][1] * y + T[r][3];
+      if constexpr (DIM == 3) v += T[r][2] * z;
+      p[r] = v;
+      q[r] = (double)a.tgt[DIM * (int64_t)j + r];
+    }
+    acc.add(p, q, box);
+  }
+  acc.wave_reduce(box);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) acc.store(sh[wave]);
+  __syncthreads();
+  if (threadIdx.x < kAcc) {
+    const int k = threadIdx.x;
+    constexpr int kS = AccLayout<DIM>::kSums;
+    double v = sh[0][k];
+    for (int w = 1; w < kMomThreads / 64; ++w) {
+      if (k < kS) v += sh[w][k];
+      else if (k < kS + DIM) v = fmin(v, sh[w][k]);
+      else v = fmax(v, sh[w][k]);
+    }
+    a.partials[(size_t)blockIdx.x * kAcc + k] = v;
+  }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(64)
+solve_kernel(SolveArgs a) {
+  constexpr int kAcc = AccLayout<DIM>::kTotal;
+  constexpr int kS = AccLayout<DIM>::kSums;
+  LargeState* st = a.state;
+  if (st->done) return;
+  const bool box = (a.flags & kFlagNormalize) != 0;
+  const int lane = threadIdx.x;
+  // lane-strided rows, then a shuffle tree: a fixed order for a fixed grid → reproducible
+  double v[kAcc];
+  for (int k = 0; k < kS; ++k) v[k] = 0.0;
+  for (int k = 0; k < DIM; ++k) { v[kS + k] = INFINITY; v[kS + DIM + k] = -INFINITY; }
+  for (int r = lane; r < a.rows; r += 64) {
+    const double* row = a.partials + (size_t)r * kAcc;
+    for (int k = 0; k < kS; ++k) v[k] += row[k];
+    for (int k = 0; k < DIM; ++k) { v[kS + k] = fmin(v[kS + k], row[kS + k]); v[kS + DIM + k] = fmax(v[kS + DIM + k], row[kS + DIM + k]); }
+  }
+  for (int k = 0; k < kS; ++k) v[k] = wave_sum(v[k]);
+  for (int k = 0; k < DIM; ++k) { v[kS + k] = wave_min(v[kS + k]); v[kS + DIM + k] = wave_max(v[kS + DIM + k]); }
+  if (lane != 0) return;
+
+  Moments mo;
+  combine_partials<DIM>(v, 1, kAcc, box, mo);
+  double Tstep[16], Tprev[16], Tnew[16];
+  step_from_moments(mo, DIM == 2, Tstep);
+  for (int i = 0; i < 16; ++i) Tprev[i] = st->T[i];
+  matmul4(Tstep, Tprev, Tnew);
+  for (int i = 0; i < 16; ++i) st->T[i] = Tnew[i];
+  const double err = error_from_moments(mo, box);
+  st->err = err;
+  StopState ss = st->stop;
+  const bool stop = stop_after_iteration(ss, err, a.epsilon, a.stopping_thresh, a.max_iters);
+  st->stop = ss;
+  if (stop) st->done = 1;
+}
+
+// ---- launchers -----------------------------------------------------------------------------------
+void nn_geometry(int dim, int64_t n, int64_t m, int* P, dim3* grid, int* tile_points, size_t* smem) {
+  const int CHUNK = (dim == 2) ? IcpChunk<2>::value : IcpChunk<3>::value;
+  *P = (n >= 4 * 256 * kNnThreads) ? 4 : 2;
+  const int64_t per_block = (int64_t)kNnThreads * (*P);
+  const int64_t sb = (n + per_block - 1) / per_block;
+  const int64_t chunks = (m + CHUNK - 1) / CHUNK;
+  // enough workgroups to fill 256 CUs a few times over, but never a split smaller than one tile
+  int64_t splits = (4 * 256 + sb - 1) / sb;
+  const int tile = (dim == 2) ? kNnTilePlanar : kNnTile3D;
+  const int64_t max_splits = (chunks * CHUNK + tile - 1) / tile;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  if (splits > 65535) splits = 65535;
+  *grid = dim3((unsigned)sb, (unsigned)splits);
+  *tile_points = tile;
+  *smem = (size_t)tile * ((dim == 2) ? 8 : 16);
+}
+
+hipError_t launch_nn(NnArgs a, int dim, hipStream_t stream) {
+  int P; dim3 grid; int tile; size_t smem;
+  nn_geometry(dim, a.n, a.m, &P, &grid, &tile, &smem);
+  a.tile_points = tile;
+  if (a.n <= 0) return hipSuccess;
+  if (dim == 2) {
+    if (P == 2) hipLaunchKernelGGL((nn_tiled_kernel<2, 2>), grid, dim3(kNnThreads), smem, stream, a);
+    else hipLaunchKernelGGL((nn_tiled_kernel<2, 4>), grid, dim3(kNnThreads), smem, stream, a);
+  } else {
+    if (P == 2) hipLaunchKernelGGL((nn_tiled_kernel<3, 2>), grid, dim3(kNnThreads), smem, stream, a);
+    else hipLaunchKernelGGL((nn_tiled_kernel<3, 4>), grid, dim3(kNnThreads), smem, stream, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_keys_init(unsigned long long* keys, int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(keys_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, keys, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_nn_finalize(unsigned long long* keys, int64_t n, int32_t* out_idx, float* out_d2, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(nn_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, keys, n, out_idx, out_d2);
+  return hipGetLastError();
+}
+
+int moments_rows(int64_t n) {
+  int64_t b = (n + kMomThreads - 1) / kMomThreads;
+  if (b > kMomMaxBlocks) b = kMomMaxBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+hipError_t launch_moments(MomArgs a, int dim, int rows, hipStream_t stream) {
+  if (dim == 2) hipLaunchKernelGGL(moments_kernel<2>, dim3(rows), dim3(kMomThreads), 0, stream, a);
+  else hipLaunchKernelGGL(moments_kernel<3>, dim3(rows), dim3(kMomThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_solve(SolveArgs a, int dim, hipStream_t stream) {
+  if (dim == 2) hipLaunchKernelGGL(solve_kernel<2>, dim3(1), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL(solve_kernel<3>, dim3(1), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace lslam

@@ -1,0 +1,130 @@
+// lslam_kernels.h — host-visible launch interface of the HIP kernels (internal to the library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lslam_solve.h"
+
+namespace lslam {
+
+constexpr int kIcpBatchMaxThreads = 1024;
+constexpr int kIcpBatchMaxWaves = kIcpBatchMaxThreads / 64;
+constexpr int kIcpTileMaxPlanar = 8192;   // points per LDS tile (64 KiB as float2)
+constexpr int kIcpTileMax3D = 4096;       // 64 KiB as float4
+constexpr uint32_t kFlagNormalize = 1u;   // == LSLAM_ICP_NORMALIZE_ERROR
+
+// targets examined per (min, chunk-id) record; the fix-up pass re-evaluates one chunk per source
+template <int DIM> struct IcpChunk;
+template <> struct IcpChunk<2> { static constexpr int value = 16; };
+template <> struct IcpChunk<3> { static constexpr int value = 8; };
+
+struct IcpBatchArgs {
+  const float* src;          // device, DIM floats per point
+  const int64_t* src_off;    // device, S+1 point offsets
+  const float* tgt;
+  const int64_t* tgt_off;
+  const double* init_T;      // device, S x 16
+  double* out_T;             // device, S x 16
+  double* out_err;           // device, S
+  int32_t* out_iters;        // device, S
+  int32_t* out_corr;         // device or nullptr, laid out like src_off
+  double epsilon;
+  double stopping_thresh;
+  int32_t max_iters;
+  uint32_t flags;
+  int32_t tile_points;       // filled by the launcher
+  uint32_t tile_bytes;       // filled by the launcher
+};
+
+struct IcpBatchTuning {
+  int points_per_lane = 0;   // 0 = heuristic; 1, 2 or 4
+  int threads = 0;           // 0 = from max_src_n
+  int tile_points = 0;       // 0 = default cap
+};
+
+hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, int64_t max_tgt_n,
+                            const IcpBatchTuning& tune, hipStream_t stream);
+
+// ---- one large pair (lslam_icp_large.hip) ---------------------------------------------------------
+constexpr int kNnThreads = 256;
+constexpr int kNnTilePlanar = 4096;   // 32 KiB of LDS per workgroup → 4 workgroups per CU
+constexpr int kNnTile3D = 2048;       // 32 KiB
+constexpr int kMomThreads = 256;
+constexpr int kMomMaxBlocks = 1024;
+
+struct LargeState {          // lives in device memory for the whole run of one problem
+  double T[16];
+  double err;
+  StopState stop;
+  int32_t done;
+};
+
+struct NnArgs {
+  const float* src; int64_t n;
+  const float* tgt; int64_t m;
+  unsigned long long* keys;      // n packed (d² bits << 32 | index), pre-set to ~0
+  const LargeState* state;       // transform + done flag, or nullptr → use T below
+  double T[16];
+  int32_t tile_points;           // filled by the launcher
+};
+
+struct MomArgs {
+  const float* src; int64_t n;
+  const float* tgt;
+  unsigned long long* keys;
+  const LargeState* state;
+  double* partials;              // rows x AccLayout<DIM>::kTotal
+  int32_t* out_corr;             // or nullptr
+  uint32_t flags;
+};
+
+struct SolveArgs {
+  LargeState* state;
+  const double* partials;
+  int32_t rows;
+  uint32_t flags;
+  double epsilon, stopping_thresh;
+  int32_t max_iters;
+};
+
+hipError_t launch_nn(NnArgs a, int dim, hipStream_t stream);
+hipError_t launch_keys_init(unsigned long long* keys, int64_t n, hipStream_t stream);
+hipError_t launch_nn_finalize(unsigned long long* keys, int64_t n, int32_t* out_idx, float* out_d2, hipStream_t stream);
+int moments_rows(int64_t n);
+hipError_t launch_moments(MomArgs a, int dim, int rows, hipStream_t stream);
+hipError_t launch_solve(SolveArgs a, int dim, hipStream_t stream);
+
+// ---- float64 pair operators (lslam_ops.hip) -------------------------------------------------------
+struct PairOpArgs {
+  const double* p; int64_t p_stride;
+  const double* q; int64_t q_stride;
+  int64_t n;
+  int32_t cols;            // coordinates used per row (≤ 3)
+  int32_t normalize;
+  double* out_T;           // device, 16 doubles (or nullptr)
+  double* out_err;         // device, 1 double (or nullptr)
+};
+hipError_t launch_pair_op(const PairOpArgs& a, hipStream_t stream);
+
+// ---- occupancy grid (lslam_ogm.hip) -----------------------------------------------------------------
+struct OgmGrid {
+  float* logodds;          // width*height, [x][y]
+  int32_t* counts;         // width*height scratch, zero between scans
+  int32_t* bbox;           // 2 x {min_x, min_y, max_x, max_y}
+  int32_t width, height;
+  double res, min_x, min_y;
+  double step, clip;
+};
+struct OgmScan {
+  const double* scan_xy;   // device, n x 2
+  int32_t n;
+  double x, y, c, s;       // pose, cos/sin of yaw
+  int32_t parity;          // which bbox slot this scan uses
+};
+hipError_t launch_ogm_raycast(const OgmGrid& g, const OgmScan& sc, hipStream_t stream);
+hipError_t launch_ogm_apply(const OgmGrid& g, int parity, hipStream_t stream);
+hipError_t launch_ogm_clear_counts(const OgmGrid& g, int parity, hipStream_t stream);
+hipError_t launch_ogm_binarize(const OgmGrid& g, uint8_t* out, hipStream_t stream);
+hipError_t launch_ogm_init(const OgmGrid& g, hipStream_t stream);
+
+}  // namespace lslam

@@ -1,0 +1,87 @@
+"""The C-ABI library loads and exports every symbol include/lslam.h declares (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, split
+
+HEADER = os.path.join(ROOT, "include", "lslam.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lslam_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ("lslam_icp_batch", "lslam_icp_batch_dev", "lslam_icp_large_dev", "lslam_nn_dev",
+                 "lslam_kabsch", "lslam_sq_error", "lslam_ogm_create", "lslam_ogm_update",
+                 "lslam_ogm_scan_counts", "lslam_last_error", "lslam_device_count"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from lidar_slam_amd import _lib
+    handle = _lib.lib()
+    for name in declared_functions():
+        assert hasattr(handle, name), f"{name} declared in lslam.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in _lib.py"
+    assert handle.lslam_abi_version() == 1
+    assert handle.lslam_device_count() >= 0
+
+
+def test_argument_validation_needs_no_gpu():
+    """bad arguments are rejected before any HIP call, with the reference's exception types"""
+    from lidar_slam_amd.batch import icp_batch
+    pts = np.zeros((4, 2), dtype=np.float32)
+    off = np.array([0, 4], dtype=np.int64)
+    with pytest.raises(IndexError):                       # empty target: reference raises IndexError
+        icp_batch(pts, off, np.zeros((0, 2), np.float32), np.array([0, 0], np.int64), np.eye(4)[None])
+    bad = pts.copy(); bad[1, 0] = np.nan
+    with pytest.raises(ValueError):                       # NaN: reference raises ValueError (KDTree)
+        icp_batch(bad, off, pts, off, np.eye(4)[None])
+    with pytest.raises(ValueError):
+        icp_batch(np.zeros((4, 5), np.float32), off, pts, off, np.eye(4)[None])
+
+
+def test_no_silent_cpu_fallback_without_a_device():
+    import lidar_slam_amd
+    if lidar_slam_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    from lidar_slam_amd.modules import icp
+    with pytest.raises(lidar_slam_amd.LslamError):
+        icp.run_icp(np.random.rand(8, 2), np.random.rand(8, 2))
+
+
+def test_solver_header_on_host_matches_reference_kabsch():
+    """lslam_solve.h (the code lane 0 runs on the GPU) compiled for the host vs golden get_transform."""
+    so = os.path.join(ROOT, "lidar_slam_amd", "lib", "liblslam_hostcheck.so")
+    h = ctypes.CDLL(so)
+    h.lslam_hostcheck_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    g = golden("kabsch.npz")
+    n_planar = int(g["n_planar"])
+    for k, (p, q) in enumerate(zip(split(g["p"], g["off"]), split(g["q"], g["off"]))):
+        m = np.zeros(23)
+        m[0] = p.shape[0]; m[1:4] = p.sum(0); m[4:7] = q.sum(0); m[7:16] = (p.T @ q).ravel()
+        for planar in ([True, False] if (k < n_planar or p.shape[0] == 1) else [False]):
+            T = np.empty((4, 4))
+            h.lslam_hostcheck_step(m.ctypes.data_as(ctypes.c_void_p), int(planar), T.ctypes.data_as(ctypes.c_void_p))
+            np.testing.assert_allclose(T, g["T"][k], atol=1e-10, err_msg=f"case {k} planar={planar}")
+
+
+def test_stop_rules_on_host():
+    so = os.path.join(ROOT, "lidar_slam_amd", "lib", "liblslam_hostcheck.so")
+    h = ctypes.CDLL(so)
+    h.lslam_hostcheck_stop.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+    def run(errs, eps, thr, mx):
+        e = np.array(errs, dtype=np.float64)
+        return h.lslam_hostcheck_stop(e.ctypes.data_as(ctypes.c_void_p), len(errs), eps, thr, mx)
+    assert run([5, 4, 3, 2, 1, 0.5], 0.0, 0.0, 3) == 4           # max_iters + 1 iterations at most
+    assert run([5, 4, 3.99995, 1], 0.01, 1e-4, 2000) == 3        # Δ rule needs a previous error
+    assert run([0.001, 5], 0.01, 1e-4, 2000) == 1                # epsilon fires first
+    assert run([5] * 60, 0.0, 0.0, 49) == 50                     # "50 forced iterations" (I2)

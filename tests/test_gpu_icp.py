@@ -1,0 +1,250 @@
+"""Parity of the HIP ICP path (through the C ABI) with the oracle and the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import TOL_ROT, TOL_TRANS, golden, split
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def icp():
+    import lidar_slam_amd
+    assert lidar_slam_amd.device_count() >= 1, "GPU tests need a HIP device"
+    from lidar_slam_amd.modules import icp as m
+    return m
+
+
+def close_to_reference(T, T_ref):
+    """stated tolerance vs the float64 reference: 5e-5 m, 5e-6 rad (rotation entries)"""
+    assert np.abs(T[:3, 3] - T_ref[:3, 3]).max() < TOL_TRANS
+    assert np.abs(T[:3, :3] - T_ref[:3, :3]).max() < TOL_ROT
+    assert np.array_equal(T[3], T_ref[3])
+
+
+def batch_of(g, key_src="src", with_init=True):
+    from lidar_slam_amd.batch import pack_clouds
+    srcs = split(g[key_src], g["src_off"])
+    flat, off = pack_clouds(srcs)
+    S = len(srcs)
+    tgt = np.ascontiguousarray(np.tile(g["tgt"], (S, 1)), dtype=np.float32)
+    toff = np.arange(S + 1, dtype=np.int64) * g["tgt"].shape[0]
+    init = g["init"] if with_init else np.tile(np.eye(4), (S, 1, 1))
+    return srcs, flat, off, tgt, toff, init
+
+
+def test_planar_pairs_batched_vs_golden_and_oracle(icp):
+    from lidar_slam_amd.batch import icp_batch
+    from oracle import icp_oracle
+    g = golden("icp_planar.npz")
+    srcs, flat, off, tgt, toff, init = batch_of(g)
+    r = icp_batch(flat, off, tgt, toff, init, epsilon=float(g["epsilon"]), return_correspondences=True)
+    np.testing.assert_array_equal(r.iterations, g["iterations"])          # same number of iterations
+    for k, src in enumerate(srcs):
+        close_to_reference(r.T[k], g["T"][k])
+        assert abs(r.error[k] - g["error"][k]) < 1e-6 * max(1.0, g["error"][k])
+        o = icp_oracle.run_icp_full(src, g["tgt"], init[k], epsilon=float(g["epsilon"]), recipe="device")
+        np.testing.assert_array_equal(r.correspondences[off[k]:off[k + 1]], o.correspondences)   # bit-exact indices
+        np.testing.assert_allclose(r.T[k], o.T, atol=1e-10)
+        np.testing.assert_allclose(r.error[k], o.error, rtol=1e-10)
+
+
+def test_run_icp_call_surface(icp):
+    g = golden("icp_planar.npz")
+    src = g["src"][: g["src_off"][1]]
+    src_before = src.copy()
+    T = icp.run_icp(src, g["tgt"], init_transform=g["init"][0], epsilon=0.001)
+    assert isinstance(T, np.ndarray) and T.shape == (4, 4) and T.dtype == np.float64
+    T2, e = icp.run_icp(src, g["tgt"], g["init"][0], 0.001, return_error=True)
+    T3, c = icp.run_icp(src, g["tgt"], g["init"][0], 0.001, return_correspondences=True)
+    T4, e4, c4 = icp.run_icp(src, g["tgt"], g["init"][0], 0.001, return_error=True, return_correspondences=True)
+    assert np.array_equal(T, T2) and np.array_equal(T, T3) and np.array_equal(T, T4)
+    assert e == e4 and isinstance(e, np.float64) and c.dtype == np.int64 and np.array_equal(c, c4)
+    assert np.array_equal(src, src_before)                     # inputs never mutated (I8)
+    close_to_reference(T, g["T"][0])
+    # float32 input is accepted (promoted in the reference)
+    close_to_reference(icp.run_icp(src.astype(np.float32), g["tgt"].astype(np.float32), g["init"][0], 0.001), g["T"][0])
+
+
+def test_forced_50_iterations(icp):
+    from lidar_slam_amd.batch import icp_batch
+    g = golden("icp_forced50.npz")
+    srcs, flat, off, tgt, toff, init = batch_of(g)
+    r = icp_batch(flat, off, tgt, toff, init, epsilon=0.0, stopping_thresh=0.0, max_iters=49)
+    assert r.iterations.tolist() == [50, 50]
+    for k in range(2):
+        close_to_reference(r.T[k], g["T"][k])
+
+
+def test_loop_closure_style_normalized_error(icp):
+    g = golden("icp_loopclose.npz")
+    srcs, corrs = split(g["src"], g["src_off"]), split(g["corr"], g["src_off"])
+    for k, src in enumerate(srcs):
+        T, err, corr = icp.run_icp(src, g["tgt"], epsilon=float(g["epsilon"][k]), return_error=True,
+                                   normalize_error=True, return_correspondences=True)
+        close_to_reference(T, g["T"][k])
+        assert abs(err - g["error"][k]) < 1e-6 * g["error"][k] + 1e-12
+        assert np.mean(corr == corrs[k]) > 0.995
+
+
+def test_3d_multistart_vs_golden_and_oracle(icp):
+    from lidar_slam_amd.batch import icp_batch
+    from oracle import c_oracle
+    g = golden("icp_3d.npz")
+    S = g["init"].shape[0]
+    n, m = g["src"].shape[0], g["tgt"].shape[0]
+    src = np.ascontiguousarray(np.tile(g["src"], (S, 1)), dtype=np.float32)
+    tgt = np.ascontiguousarray(np.tile(g["tgt"], (S, 1)), dtype=np.float32)
+    r = icp_batch(src, np.arange(S + 1) * n, tgt, np.arange(S + 1) * m, g["init"], epsilon=0.001,
+                  normalize_error=True, return_correspondences=True)
+    np.testing.assert_array_equal(r.iterations, g["iterations"])
+    for k in range(S):
+        close_to_reference(r.T[k], g["T"][k])
+        To, eo, co, ito = c_oracle.run_icp(g["src"], g["tgt"], g["init"][k], epsilon=0.001, normalize_error=True,
+                                           recipe="device")
+        np.testing.assert_array_equal(r.correspondences[k * n:(k + 1) * n], co)
+        np.testing.assert_allclose(r.T[k], To, atol=1e-9)
+        np.testing.assert_allclose(r.error[k], eo, rtol=1e-9)
+
+
+def test_get_transform_get_error_get_correspondences(icp):
+    from oracle import c_oracle
+    g = golden("kabsch.npz")
+    for k, (p, q) in enumerate(zip(split(g["p"], g["off"]), split(g["q"], g["off"]))):
+        np.testing.assert_allclose(icp.get_transform(p, q), g["T"][k], atol=1e-10)
+    rng = np.random.default_rng(1)
+    p, q = rng.normal(size=(777, 3)), rng.normal(size=(777, 3))
+    assert abs(icp.get_error(p, q) - np.sum((p - q) ** 2)) < 1e-9
+    both = np.vstack((p, q)); diag2 = np.sum((both.max(0) - both.min(0)) ** 2)
+    assert abs(icp.get_error(p, q, normalize=True) - np.sum((p - q) ** 2) / (diag2 * 777)) < 1e-12
+    tgt = rng.uniform(-5, 5, (5000, 3))
+    idx = icp.get_correspondences(p, icp.TargetCloud(tgt))
+    ref, _ = c_oracle.nn_f32(p.astype(np.float32), tgt.astype(np.float32))
+    assert idx.dtype == np.int64 and np.array_equal(idx, ref)
+
+
+def test_icp_iteration_is_one_step(icp):
+    from oracle import icp_oracle
+    g = golden("icp_planar.npz")
+    src = icp_oracle.as_xyz(g["src"][: g["src_off"][1]])
+    tgt = icp_oracle.as_xyz(g["tgt"])
+    T, corr, err = icp.icp_iteration(np.hstack((src, np.ones((src.shape[0], 1)))),
+                                     np.hstack((tgt, np.ones((tgt.shape[0], 1)))), icp.TargetCloud(tgt), g["init"][0])
+    To, co, eo = icp_oracle.icp_iteration(src, tgt, g["init"][0], recipe="device", planar=False)
+    np.testing.assert_array_equal(corr, co)
+    np.testing.assert_allclose(T, To, atol=1e-10)
+    np.testing.assert_allclose(err, eo, rtol=1e-10)
+
+
+def test_errors_match_the_reference(icp):
+    g = golden("icp_planar.npz")
+    src = g["src"][:100]
+    with pytest.raises(IndexError):
+        icp.run_icp(src, np.zeros((0, 2)))
+    bad = src.copy(); bad[7, 1] = np.inf
+    with pytest.raises(ValueError):
+        icp.run_icp(bad, g["tgt"])
+    T, err, corr = icp.run_icp(np.zeros((0, 2)), g["tgt"], return_error=True, return_correspondences=True)
+    assert np.all(np.isnan(T[:3])) and np.array_equal(T[3], [0, 0, 0, 1]) and err == 0.0 and corr.size == 0
+
+
+def test_scan_matching_sequence_vs_golden(icp):
+    from lidar_slam_amd.modules.localization import poses_from_scan_matching, scan_matching_relative_poses
+    g = golden("seq_scanmatch.npz")
+    z = split(g["z"], g["z_off"])
+    poses, rel = poses_from_scan_matching(g["x_ts"], z, return_relative_poses=True)
+    assert poses.shape == g["poses"].shape and rel.shape == g["relative_poses"].shape
+    assert np.abs(rel[:, :2, 2] - g["relative_poses"][:, :2, 2]).max() < TOL_TRANS
+    assert np.abs(rel[:, :2, :2] - g["relative_poses"][:, :2, :2]).max() < TOL_ROT
+    assert np.abs(poses[:, :2] - g["poses"][:, :2]).max() < 31 * TOL_TRANS
+    _, info = scan_matching_relative_poses(g["x_ts"], z, return_info=True)
+    assert int(info.iterations.sum()) == int(g["total_iterations"])
+    assert np.array_equal(poses_from_scan_matching(g["x_ts"], z), poses)
+
+
+@pytest.mark.parametrize("env", [{"LSLAM_ICP_POINTS_PER_LANE": "1"}, {"LSLAM_ICP_POINTS_PER_LANE": "4"},
+                                 {"LSLAM_ICP_TILE_POINTS": "256"}, {"LSLAM_ICP_THREADS": "128"},
+                                 {"LSLAM_ICP_TILE_POINTS": "128", "LSLAM_ICP_THREADS": "64", "LSLAM_ICP_POINTS_PER_LANE": "2"}])
+def test_launch_geometry_does_not_change_results(icp, env, monkeypatch):
+    """register blocking, multi-pass sources and multi-tile targets all give the same answers"""
+    from lidar_slam_amd.batch import icp_batch
+    g = golden("icp_planar.npz")
+    srcs, flat, off, tgt, toff, init = batch_of(g)
+    base = icp_batch(flat, off, tgt, toff, init, epsilon=0.001, return_correspondences=True)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = icp_batch(flat, off, tgt, toff, init, epsilon=0.001, return_correspondences=True)
+    np.testing.assert_array_equal(r.iterations, base.iterations)
+    np.testing.assert_array_equal(r.correspondences, base.correspondences)
+    np.testing.assert_allclose(r.T, base.T, atol=1e-11)
+
+
+def test_large_path_equals_batch_path(icp):
+    """the whole-chip path (3 launches / iteration) and the one-workgroup path agree"""
+    from lidar_slam_amd import _lib
+    from lidar_slam_amd._lib import check, lib, ptr
+    g = golden("icp_planar.npz")
+    src = np.ascontiguousarray(g["src"][: g["src_off"][1]], dtype=np.float32)
+    tgt = np.ascontiguousarray(g["tgt"], dtype=np.float32)
+    for dim, norm in ((2, False), (3, True)):
+        s = src if dim == 2 else np.ascontiguousarray(np.hstack((src, np.zeros((src.shape[0], 1), np.float32))))
+        t = tgt if dim == 2 else np.ascontiguousarray(np.hstack((tgt, np.zeros((tgt.shape[0], 1), np.float32))))
+        T = np.empty((4, 4)); err = np.empty(1); it = np.empty(1, np.int32); corr = np.empty(s.shape[0], np.int32)
+        T0 = np.ascontiguousarray(g["init"][0])
+        check(lib().lslam_icp_large(ptr(s), s.shape[0], ptr(t), t.shape[0], dim, ptr(T0), 1e-3 if not norm else 1e-7,
+                                    1e-4, 2000, _lib.ICP_NORMALIZE_ERROR if norm else 0, ptr(T), ptr(err), ptr(it),
+                                    ptr(corr), 0))
+        from lidar_slam_amd.batch import icp_batch
+        r = icp_batch(s, [0, s.shape[0]], t, [0, t.shape[0]], T0[None], epsilon=1e-3 if not norm else 1e-7,
+                      normalize_error=norm, return_correspondences=True)
+        assert it[0] == r.iterations[0]
+        np.testing.assert_array_equal(corr, r.correspondences)
+        np.testing.assert_allclose(T, r.T[0], atol=1e-10)
+        np.testing.assert_allclose(err[0], r.error[0], rtol=1e-9)
+
+
+def test_full_size_batch_properties(icp):
+    """BASELINE config sizes (4096 × 4096 planar), checked through size-independent properties:
+    a known rigid motion is recovered; results do not depend on which other problems share the launch;
+    permuting the target permutes the correspondences and leaves the pose alone."""
+    from lidar_slam_amd.batch import icp_batch
+    from lidar_slam_amd.synth import batch_c4
+    S = 48
+    w = batch_c4(S, 4096, seed=123)
+    r = icp_batch(w.src, w.src_off, w.tgt, w.tgt_off, w.init_T, epsilon=1e-3, return_correspondences=True)
+    err_t = np.abs(r.T[:, :2, 3] - w.true_T[:, :2, 3]).max()
+    err_R = np.abs(r.T[:, :2, :2] - w.true_T[:, :2, :2]).max()
+    assert err_t < 2e-3 and err_R < 2e-4, (err_t, err_R)              # 1 cm noise on 4096 points
+    sub = slice(5 * 4096, 6 * 4096)
+    one = icp_batch(w.src[sub], [0, 4096], w.tgt[sub], [0, 4096], w.init_T[5:6], epsilon=1e-3, return_correspondences=True)
+    assert one.iterations[0] == r.iterations[5]
+    np.testing.assert_array_equal(one.correspondences, r.correspondences[sub])
+    np.testing.assert_array_equal(one.T[0], r.T[5])                   # bitwise: fixed-order reductions
+    perm = np.random.default_rng(0).permutation(4096)
+    pt = icp_batch(w.src[sub], [0, 4096], np.ascontiguousarray(w.tgt[sub][perm]), [0, 4096], w.init_T[5:6],
+                   epsilon=1e-3, return_correspondences=True)
+    assert pt.iterations[0] == one.iterations[0]
+    np.testing.assert_array_equal(perm[pt.correspondences], one.correspondences)
+    np.testing.assert_allclose(pt.T[0], one.T[0], atol=1e-12)
+
+
+def test_dense_3d_nn_against_exact_c_oracle(icp):
+    """100k-style 3-D search (here 20k × 50k so that the CPU oracle finishes in seconds): every index exact"""
+    import torch
+    from lidar_slam_amd.batch import nn_dev
+    from oracle import c_oracle
+    rng = np.random.default_rng(5)
+    src = rng.normal(size=(20000, 3)).astype(np.float32)
+    tgt = rng.normal(size=(50000, 3)).astype(np.float32)
+    tgt[1000:1010] = tgt[10:20]                       # exact duplicates: lowest index must win
+    d_s, d_t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    idx = torch.empty(src.shape[0], dtype=torch.int32, device="cuda")
+    d2 = torch.empty(src.shape[0], dtype=torch.float32, device="cuda")
+    nn_dev(d_s.data_ptr(), src.shape[0], d_t.data_ptr(), tgt.shape[0], 3, None, idx.data_ptr(), d2.data_ptr(),
+           stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref_idx, ref_d2 = c_oracle.nn_f32(src, tgt)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx)
+    np.testing.assert_array_equal(d2.cpu().numpy(), ref_d2)

@@ -1,0 +1,88 @@
+"""Parity of the HIP occupancy-grid path with the reference's golden grids and the oracle."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def make(g):
+    from lidar_slam_amd.modules.ogm import OccupancyGridMap
+    res, maxx, maxy, minx, miny, buf = g["geometry"]
+    return OccupancyGridMap(res, maxx, maxy, minx, miny, buf)
+
+
+@pytest.mark.parametrize("name", ["ogm_main.npz", "ogm_small.npz"])
+def test_hit_miss_grids_bit_exact_and_logodds(name):
+    from oracle.ogm_oracle import OccupancyGridOracle
+    g = golden(name)
+    grid = make(g)
+    assert grid.grid_map.shape == tuple(g["shape"]) and grid.grid_map_log_odds.dtype == np.float32
+    res, maxx, maxy, minx, miny, buf = g["geometry"]
+    orc = OccupancyGridOracle(res, maxx, maxy, minx, miny, buf)
+    for k, pose in enumerate(g["poses"]):
+        cnt = grid.scan_counts(pose, g["scan"])
+        lo, hi = g["cnt_off"][k], g["cnt_off"][k + 1]
+        ref = np.zeros_like(cnt)
+        ref[g["cnt_ix"][lo:hi], g["cnt_iy"][lo:hi]] = g["cnt_v"][lo:hi]
+        np.testing.assert_array_equal(cnt, ref)                    # bit-exact cells and counts vs the REFERENCE
+        before = grid.grid_map_log_odds
+        grid.update_map(pose, g["scan"])
+        orc.apply_counts(ref)
+        assert grid.grid_map_log_odds is not before                # rebinding, as ogm.py:188
+        np.testing.assert_array_equal(grid.grid_map_log_odds, orc.grid_map_log_odds)   # count form: exact
+    ref_lo = np.zeros(grid.grid_map_log_odds.shape, dtype=np.float32)
+    ref_lo[g["lo_ix"], g["lo_iy"]] = g["lo_v"]
+    np.testing.assert_allclose(grid.grid_map_log_odds, ref_lo, rtol=0, atol=1e-5)      # vs reference floats (O5)
+
+
+@pytest.mark.parametrize("name", ["ogm_main.npz", "ogm_small.npz"])
+def test_build_map(name):
+    g = golden(name)
+    grid = make(g)
+    grid.build_map(g["poses"], [g["scan"]] * len(g["poses"]))
+    ref_map = np.unpackbits(g["grid_map"])[: grid.grid_map.size].reshape(grid.grid_map.shape)
+    assert grid.grid_map.dtype == np.uint8
+    np.testing.assert_array_equal(grid.grid_map, ref_map)
+    ref_lo = np.zeros(grid.grid_map_log_odds.shape, dtype=np.float32)
+    ref_lo[g["lo_ix"], g["lo_iy"]] = g["lo_v"]
+    np.testing.assert_allclose(grid.grid_map_log_odds, ref_lo, rtol=0, atol=1e-5)
+
+
+def test_helpers_and_attribute_surface():
+    g = golden("bresenham.npz")
+    from conftest import split
+    from lidar_slam_amd.modules.ogm import OccupancyGridMap
+    grid = OccupancyGridMap(0.05, 30, 30, -30, -30)
+    assert (grid.grid_map_width, grid.grid_map_height) == (1201, 1201)
+    assert grid.world2grid(0.0, 0.0).tolist() == [599, 599] and abs(grid.logodds_ratio - np.log(4.0)) < 1e-15
+    for ray, cells in zip(g["rays"], split(g["cells"], g["off"])):
+        np.testing.assert_array_equal(grid.bresenham2D(*ray), cells)
+    # setting the public attributes works like on the reference object
+    grid.logodds_ratio = 0.5
+    grid.update_map(np.zeros(3), np.array([[1.0, 0.0]]))
+    lo = grid.grid_map_log_odds
+    assert lo.max() == np.float32(0.5) and lo.min() == np.float32(-0.5)
+    grid.grid_map_log_odds = np.full((1201, 1201), 3.0, dtype=np.float32)
+    grid.update_map(np.zeros(3), np.zeros((0, 2)))
+    assert np.all(grid.grid_map_log_odds == 3.0)
+
+
+def test_sequence_order_and_clip_random_scans():
+    """many scans through the same cells: saturation at ±20 and scan order are honoured"""
+    from lidar_slam_amd.modules.ogm import OccupancyGridMap
+    from oracle.ogm_oracle import OccupancyGridOracle
+    rng = np.random.default_rng(11)
+    grid = OccupancyGridMap(0.1, 10, 10, -10, -10)
+    orc = OccupancyGridOracle(0.1, 10, 10, -10, -10)
+    poses, scans = [], []
+    for _ in range(40):
+        poses.append([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-3, 3)])
+        a = rng.uniform(-2.3, 2.3, 300); r = rng.uniform(0.5, 14, 300)
+        scans.append(np.column_stack((r * np.cos(a), r * np.sin(a))))
+    grid.build_map(np.array(poses), scans)
+    orc.build_map(np.array(poses), scans)
+    assert np.abs(orc.grid_map_log_odds).max() == 20.0
+    np.testing.assert_array_equal(grid.grid_map_log_odds, orc.grid_map_log_odds)
+    np.testing.assert_array_equal(grid.grid_map, orc.grid_map)
