@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py — ICP scan-matching throughput on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+Default workload = BASELINE.json configs[3] ("synthetic batch: 4096 scan-pairs × 4096 pts each",
+the configuration the multi-GPU part of the metric is quoted on; it fits one GPU): per GPU S = 4096
+independent planar ICP problems, N = M = 4096, exactly 50 iterations each (epsilon = 0,
+stopping_thresh = 0, max_iters = 49 — the reference API's way to force the count).
+One *step* = one pass of the hot path over that batch (one `lslam_icp_batch_dev` launch) plus, for
+N > 1, the all-gather of the S×16 float64 relative transforms over RCCL.  Weak scaling: every rank
+owns its own 4096 pairs.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload c4|c2|c3|c5] [--pairs S --points P --iters I]
+
+Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel, HIP-event timed),
+`cpu_baseline` (the oracle's SciPy-KDTree port timed on this box's host cores, N = 1 only) and
+`other_configs` (C2 / C3 / C5 one-shot timings, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_VECTOR_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CUs × 4 SIMD × 32 lanes × 2 flop × 2.4 GHz
+PEAK_HBM_TBS = 8.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5"])
+    ap.add_argument("--pairs", type=int, default=4096, help="scan pairs per GPU (c4)")
+    ap.add_argument("--points", type=int, default=4096, help="points per cloud (c4)")
+    ap.add_argument("--iters", type=int, default=50, help="forced ICP iterations per pair (c4/c2/c5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=96)
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------- workloads
+def make_c4_on_device(torch, S, P, seed, device):
+    """SURVEY §8(d) C4, generated straight into HBM: target ~ U(−10,10)², source = per-pair random
+    SE(2) (|t| ≤ 0.3, |θ| ≤ 0.1) of it + N(0, 1 cm), init = truth + N(5 mm, 3 mrad)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    tgt = (torch.rand((S, P, 2), generator=g, device=device, dtype=torch.float64) * 20.0 - 10.0)
+    th = (torch.rand((S,), generator=g, device=device, dtype=torch.float64) * 0.2 - 0.1)
+    t = (torch.rand((S, 2), generator=g, device=device, dtype=torch.float64) * 0.6 - 0.3)
+    c, s = torch.cos(th), torch.sin(th)
+    R = torch.stack((torch.stack((c, -s), -1), torch.stack((s, c), -1)), -2)          # (S,2,2): src -> tgt
+    noise = torch.randn((S, P, 2), generator=g, device=device, dtype=torch.float64) * 0.01
+    src = torch.einsum("sij,spi->spj", R, tgt - t[:, None, :]) + noise                 # Rᵀ (q − t)
+    e = torch.randn((S, 3), generator=g, device=device, dtype=torch.float64) * torch.tensor([0.005, 0.005, 0.003], device=device, dtype=torch.float64)
+    thi, ti = th + e[:, 2], t + e[:, :2]
+    init = torch.zeros((S, 4, 4), device=device, dtype=torch.float64)
+    init[:, 0, 0] = torch.cos(thi); init[:, 0, 1] = -torch.sin(thi)
+    init[:, 1, 0] = torch.sin(thi); init[:, 1, 1] = torch.cos(thi)
+    init[:, 0, 3] = ti[:, 0]; init[:, 1, 3] = ti[:, 1]; init[:, 2, 2] = 1; init[:, 3, 3] = 1
+    off = torch.arange(S + 1, device=device, dtype=torch.int64) * P
+    return (src.reshape(S * P, 2).to(torch.float32).contiguous(), tgt.reshape(S * P, 2).to(torch.float32).contiguous(),
+            off, init.contiguous(), (th, t))
+
+
+def cpu_baseline_icp(src, tgt, init, P, n_pairs, iters):
+    """The oracle's KDTree port of modules/icp.py (same algorithm and complexity as the reference),
+    one process — the reference's real behaviour — on the first n_pairs of the workload."""
+    from oracle import icp_oracle
+    t0 = time.perf_counter()
+    total_it = 0
+    for k in range(n_pairs):
+        r = icp_oracle.run_icp_full(src[k * P:(k + 1) * P], tgt[k * P:(k + 1) * P], init[k], epsilon=0.0,
+                                    stopping_thresh=0.0, max_iters=iters - 1, nn="kdtree")
+        total_it += r.iterations
+    dt = time.perf_counter() - t0
+    return total_it / dt, dt, total_it
+
+
+def _pool_job(args):
+    from oracle import icp_oracle
+    src, tgt, init, iters = args
+    return icp_oracle.run_icp_full(src, tgt, init, epsilon=0.0, stopping_thresh=0.0, max_iters=iters - 1).iterations
+
+
+def cpu_baseline_all_cores(src, tgt, init, P, n_pairs, iters):
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    jobs = [(src[k * P:(k + 1) * P], tgt[k * P:(k + 1) * P], init[k], iters) for k in range(n_pairs)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        total = sum(pool.map(_pool_job, jobs, chunksize=1))
+    return total / (time.perf_counter() - t0), cores
+
+
+# ------------------------------------------------------------------------------------------ main
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from lidar_slam_amd import batch as B
+    from lidar_slam_amd._lib import check, lib
+    check(lib().lslam_set_device(local_rank))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    result = {}
+    if a.workload == "c4":
+        S, P, I = a.pairs, a.points, a.iters
+        src, tgt, off, init, _ = make_c4_on_device(torch, S, P, seed=1000 + rank, device=device)
+        out_T = torch.empty((S, 4, 4), device=device, dtype=torch.float64)
+        out_err = torch.empty((S,), device=device, dtype=torch.float64)
+        out_it = torch.empty((S,), device=device, dtype=torch.int32)
+        gathered = torch.empty((world * S, 4, 4), device=device, dtype=torch.float64) if world > 1 else None
+
+        def step():
+            B.icp_batch_dev(src.data_ptr(), off.data_ptr(), tgt.data_ptr(), off.data_ptr(), 2, init.data_ptr(), S, P, P,
+                            out_T.data_ptr(), out_err.data_ptr(), out_it.data_ptr(), None, epsilon=0.0,
+                            max_iters=I - 1, stopping_thresh=0.0, stream=stream)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, out_T)       # the one collective: relative poses
+
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize(); barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            ev[k][0].record()
+            B.icp_batch_dev(src.data_ptr(), off.data_ptr(), tgt.data_ptr(), off.data_ptr(), 2, init.data_ptr(), S, P, P,
+                            out_T.data_ptr(), out_err.data_ptr(), out_it.data_ptr(), None, epsilon=0.0,
+                            max_iters=I - 1, stopping_thresh=0.0, stream=stream)
+            ev[k][1].record()
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, out_T)
+        torch.cuda.synchronize(); barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+        iters_done = int(out_it.sum().item())
+        assert iters_done == S * I, (iters_done, S * I)
+        total_iters = world * S * I * a.steps
+        pair_evals_per_launch = float(S) * I * P * P
+        flops = 5.0 * pair_evals_per_launch                        # 3d − 1 per pair evaluation, d = 2
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        result = {
+            "metric": "icp_iterations_per_sec", "value": total_iters / dt, "unit": "iterations/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C4 synthetic batch: {S} scan pairs per GPU x {P}x{P} planar points, {I} forced ICP iterations per pair",
+                       "pairs_per_gpu": S, "points": P, "iterations": I, "sharding": f"independent pairs over {world} GPU(s), all-gather of poses"},
+            "scan_pairs_per_sec": world * S * a.steps / dt,
+            "pair_evals_per_sec": world * pair_evals_per_launch * a.steps / dt,
+            "roofline": {"kernel": "icp_batch_kernel<2,4>", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None,
+                         "kernel_ms": kernel_ms, "algorithmic_flop_per_pair_eval": 5,
+                         "pair_evals_per_s": pair_evals_per_launch / (kernel_ms * 1e-3),
+                         "hbm_effective_untiled_TBps": pair_evals_per_launch * 8 / (kernel_ms * 1e-3) / 1e12,
+                         "hbm_effective_frac_of_8TBps": pair_evals_per_launch * 8 / (kernel_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                         "hbm_compulsory_bytes_per_launch": 2 * S * P * 8 + S * 2 * 128,
+                         "note": "fp32 VALU-issue bound (all-pairs NN out of LDS); HBM sees only the compulsory bytes. peak = fp32 vector peak"},
+        }
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            n = min(a.cpu_sample_pairs, S)
+            h_src, h_tgt, h_init = src[: n * P].cpu().numpy().astype(np.float64), tgt[: n * P].cpu().numpy().astype(np.float64), init[:n].cpu().numpy()
+            v, secs, its = cpu_baseline_icp(h_src, h_tgt, h_init, P, n, I)
+            vall, cores = cpu_baseline_all_cores(h_src, h_tgt, h_init, P, n, I)
+            result["cpu_baseline"] = {"value": v, "unit": "iterations/s", "cores": 1, "kind": "port",
+                                      "sample": f"first {n} of the {S} pairs, {I} forced iterations each, oracle KDTree port of modules/icp.py, {secs:.1f} s",
+                                      "all_cores_value": vall, "all_cores": cores}
+    else:
+        result = other_config(a.workload, a, torch, device, stream, timed=True)
+
+    if rank == 0 and world == 1 and a.workload == "c4" and not a.no_other_configs:
+        result["other_configs"] = {k: other_config(k, a, torch, device, stream, timed=False) for k in ("c2", "c3", "c5")}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def other_config(name, a, torch, device, stream, timed):
+    """one-shot timings of the other BASELINE configs (not the headline line)"""
+    from lidar_slam_amd import batch as B
+    from lidar_slam_amd import synth
+    out = {}
+    if name == "c2":
+        src, tgt, T_true = synth.pair_c2(0)
+        s = torch.from_numpy(src.astype(np.float32)).to(device); t = torch.from_numpy(tgt.astype(np.float32)).to(device)
+        off = torch.tensor([0, 1081], device=device, dtype=torch.int64)
+        init = torch.eye(4, device=device, dtype=torch.float64)[None].contiguous()
+        oT = torch.empty((1, 4, 4), device=device, dtype=torch.float64); oe = torch.empty(1, device=device, dtype=torch.float64)
+        oi = torch.empty(1, device=device, dtype=torch.int32)
+        def run():
+            B.icp_batch_dev(s.data_ptr(), off.data_ptr(), t.data_ptr(), off.data_ptr(), 2, init.data_ptr(), 1, 1081, 1081,
+                            oT.data_ptr(), oe.data_ptr(), oi.data_ptr(), None, epsilon=0.0, max_iters=a.iters - 1,
+                            stopping_thresh=0.0, stream=stream)
+        ms = _time(torch, run, 3, 20)
+        out = {"workload": "C2 single planar pair 1081x1081, 50 forced iterations, one workgroup", "ms": ms,
+               "iterations_per_sec": a.iters / (ms * 1e-3), "pose_err_vs_truth": float(np.abs(oT[0].cpu().numpy() - T_true).max())}
+    elif name == "c5":
+        src, tgt, T_true, T0 = synth.cloud_c5()
+        s = torch.from_numpy(src).to(device); t = torch.from_numpy(tgt).to(device)
+        res = {}
+        def run():
+            res["r"] = B.icp_large_dev(s.data_ptr(), s.shape[0], t.data_ptr(), t.shape[0], 3, T0, epsilon=0.0, max_iters=19,
+                                       stopping_thresh=0.0, poll_every=20, stream=stream)
+        ms = _time(torch, run, 1, 3)
+        T, err, it = res["r"]
+        out = {"workload": "C5 dense 3-D 100k x 100k, 20 forced iterations, whole chip", "ms": ms, "iterations": it,
+               "iterations_per_sec": it / (ms * 1e-3), "pair_evals_per_sec": it * 1e10 / (ms * 1e-3),
+               "valu_tflops_alg": it * 1e10 * 8 / (ms * 1e-3) / 1e12, "pose_err_vs_truth": float(np.abs(T - T_true).max())}
+    elif name == "c3":
+        from lidar_slam_amd.modules.localization import scan_matching_relative_poses, chain_poses
+        t0 = time.perf_counter()
+        seq = synth.sequence_c3(4956, seed=20)
+        gen_s = time.perf_counter() - t0
+        scan_matching_relative_poses(seq.x_ts[:64], seq.z_ts[:64])                     # warm-up
+        t0 = time.perf_counter()
+        rel, info = scan_matching_relative_poses(seq.x_ts, seq.z_ts, return_info=True)
+        poses = chain_poses(rel)
+        stage_s = time.perf_counter() - t0
+        # CPU baseline on a bounded sample of the same sequence (oracle KDTree port = reference algorithm)
+        from oracle import se2_oracle
+        n = 400
+        t0 = time.perf_counter()
+        _, _, it_cpu = se2_oracle.poses_from_scan_matching(seq.x_ts[:n + 1], seq.z_ts[:n + 1], return_relative_poses=True, return_iterations=True)
+        cpu_s = time.perf_counter() - t0
+        same = int(np.sum(info.iterations[:n] == it_cpu))
+        out = {"workload": "C3 dataset-20-like sequence: 4955 consecutive scan pairs (650-1081 pts), natural convergence, host arrays in/out (PCIe + chain included)",
+               "stage_seconds": stage_s, "scan_pairs_per_sec": 4955 / stage_s, "total_iterations": int(info.iterations.sum()),
+               "cpu_port_seconds_per_pair": cpu_s / n, "cpu_port_extrapolated_seconds": cpu_s / n * 4955,
+               "speedup_vs_cpu_port_1core": (cpu_s / n * 4955) / stage_s, "iteration_counts_equal_on_sample": f"{same}/{n}",
+               "synth_seconds": gen_s, "final_pose": poses[-1].tolist()}
+    return out
+
+
+def _time(torch, fn, warm, reps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+if __name__ == "__main__":
+    main()
