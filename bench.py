@@ -30,6 +30,19 @@ PEAK_FP32_VECTOR_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CUs × 4 SIMD ×
 PEAK_HBM_TBS = 8.0
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+    (profiles/rNN/pmc_traffic.json; collected with the same bench command, see that file)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))[workload]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,7 +191,8 @@ def main():
             "scan_pairs_per_sec": world * S * a.steps / dt,
             "pair_evals_per_sec": world * pair_evals_per_launch * a.steps / dt,
             "roofline": {"kernel": "icp_batch_kernel<2,4>", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                         "traffic": measured_traffic("c4") if (S, P, I) == (4096, 4096, 50) else None,
                          "kernel_ms": kernel_ms, "algorithmic_flop_per_pair_eval": 5,
                          "pair_evals_per_s": pair_evals_per_launch / (kernel_ms * 1e-3),
                          "hbm_effective_untiled_TBps": pair_evals_per_launch * 8 / (kernel_ms * 1e-3) / 1e12,

@@ -25,6 +25,13 @@ __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, f
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
+// broadcast lane 0's value through scalar registers (the value must already be wave-uniform)
+__device__ __forceinline__ double wave_uniform(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);

@@ -136,100 +136,116 @@ icp_batch_kernel(IcpBatchArgs args) {
   double err_out = 0.0;
   const int src_per_pass = blockDim.x * P;
 
-  for (;;) {
-    double T[3][4];
+  // One pass = blockDim·P source points: transform, sweep all targets, fix up the index, add the
+  // pair to the float64 moments.  Only the float32 copies of the points live across the sweep;
+  // the float64 transform is re-evaluated afterwards from the (L2-resident) source.
+  auto run_pass = [&](int base, const double (&T)[3][4], PairAcc<DIM>& acc) {
+    float a[P][DIM];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) T[r][c] = sh_T[4 * r + c];
-
-    PairAcc<DIM> acc;
-    acc.clear();
-
-    const int passes = n > 0 ? (n + src_per_pass - 1) / src_per_pass : 1;
-    for (int pass = 0; pass < passes; ++pass) {
-      const int base = pass * src_per_pass;
-      // ---- load + transform P source points (icp.py:116) -----------------------------------
-      float a[P][DIM];
-      double pd[P][DIM];
-      bool live[P];
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int i = base + p * blockDim.x + tid;
-        live[p] = i < n;
-        double x = 0.0, y = 0.0, z = 0.0;
-        if (live[p]) {
-          if constexpr (DIM == 2) {
-            const float2 v = *reinterpret_cast<const float2*>(gsrc + 2 * (int64_t)i);
-            x = v.x; y = v.y;
-          } else {
-            x = gsrc[3 * (int64_t)i]; y = gsrc[3 * (int64_t)i + 1]; z = gsrc[3 * (int64_t)i + 2];
-          }
+    for (int p = 0; p < P; ++p) {
+      const int i = base + p * blockDim.x + tid;
+      double x = 0.0, y = 0.0, z = 0.0;
+      if (i < n) {
+        if constexpr (DIM == 2) {
+          const float2 v = *reinterpret_cast<const float2*>(gsrc + 2 * (int64_t)i);
+          x = v.x; y = v.y;
+        } else {
+          x = gsrc[3 * (int64_t)i]; y = gsrc[3 * (int64_t)i + 1]; z = gsrc[3 * (int64_t)i + 2];
         }
+      }
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) {                        // icp.py:116
+        double v = T[r][0] * x + T[r][1] * y + T[r][3];
+        if constexpr (DIM == 3) v += T[r][2] * z;
+        a[p][r] = (float)v;
+      }
+    }
+
+    // ---- nearest neighbour over all targets --------------------------------------------------
+    float best[P];
+    int bchunk[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { best[p] = INFINITY; bchunk[p] = 0; }
+    if (resident) {
+      sweep_tile<DIM, P, CHUNK>(tile, (m + CHUNK - 1) / CHUNK, 0, a, best, bchunk);
+    } else {
+      for (int t = 0; t < ntiles; ++t) {
+        const int first = t * tile_cap;
+        const int cnt = min(tile_cap, m - first);
+        __syncthreads();                                     // previous tile fully consumed
+        stage_tile<DIM>(gtgt + (int64_t)DIM * first, cnt, ((cnt + CHUNK - 1) / CHUNK) * CHUNK, tile);
+        __syncthreads();
+        sweep_tile<DIM, P, CHUNK>(tile, (cnt + CHUNK - 1) / CHUNK, first / CHUNK, a, best, bchunk);
+      }
+    }
+
+    // ---- fix-up: exact index inside the winning chunk; moments in float64 --------------------
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int j0 = bchunk[p] * CHUNK;
+      float bd = INFINITY;
+      int bi = j0;
+      float q[DIM] = {};
+#pragma unroll
+      for (int k = 0; k < CHUNK; ++k) {
+        const int j = j0 + k;
+        float bx, by, bz = 0.f;
+        if (resident) {
+          const TP v = tile[j];
+          bx = v.x; by = v.y;
+          if constexpr (DIM == 3) bz = v.z;
+        } else {
+          const bool in = j < m;
+          bx = in ? gtgt[(int64_t)DIM * j] : kFar;
+          by = in ? gtgt[(int64_t)DIM * j + 1] : kFar;
+          if constexpr (DIM == 3) bz = in ? gtgt[(int64_t)DIM * j + 2] : kFar;
+        }
+        float d;
+        if constexpr (DIM == 2) d = dist2(a[p][0], a[p][1], bx, by);
+        else d = dist2(a[p][0], a[p][1], a[p][2], bx, by, bz);
+        if (d < bd || k == 0) {
+          bd = d; bi = j; q[0] = bx; q[1] = by;
+          if constexpr (DIM == 3) q[2] = bz;
+        }
+      }
+      const int i = base + p * blockDim.x + tid;
+      if (i < n) {
+        double x, y, z = 0.0;
+        if constexpr (DIM == 2) {
+          const float2 v = *reinterpret_cast<const float2*>(gsrc + 2 * (int64_t)i);
+          x = v.x; y = v.y;
+        } else {
+          x = gsrc[3 * (int64_t)i]; y = gsrc[3 * (int64_t)i + 1]; z = gsrc[3 * (int64_t)i + 2];
+        }
+        double pd[DIM], qd[DIM];
 #pragma unroll
         for (int r = 0; r < DIM; ++r) {
           double v = T[r][0] * x + T[r][1] * y + T[r][3];
           if constexpr (DIM == 3) v += T[r][2] * z;
-          pd[p][r] = v;
-          a[p][r] = (float)v;
+          pd[r] = v;
+          qd[r] = (double)q[r];
         }
+        acc.add(pd, qd, box);
+        if (args.out_corr) args.out_corr[s0 + i] = bi;
       }
+    }
+  };
 
-      // ---- nearest neighbour over all targets ----------------------------------------------
-      float best[P];
-      int bchunk[P];
+  for (;;) {
+    // the transform is wave-uniform: move it to scalar registers
+    double T[3][4];
 #pragma unroll
-      for (int p = 0; p < P; ++p) { best[p] = INFINITY; bchunk[p] = 0; }
-      if (resident) {
-        sweep_tile<DIM, P, CHUNK>(tile, (m + CHUNK - 1) / CHUNK, 0, a, best, bchunk);
-      } else {
-        for (int t = 0; t < ntiles; ++t) {
-          const int first = t * tile_cap;
-          const int cnt = min(tile_cap, m - first);
-          __syncthreads();                                   // previous tile fully consumed
-          stage_tile<DIM>(gtgt + (int64_t)DIM * first, cnt, ((cnt + CHUNK - 1) / CHUNK) * CHUNK, tile);
-          __syncthreads();
-          sweep_tile<DIM, P, CHUNK>(tile, (cnt + CHUNK - 1) / CHUNK, first / CHUNK, a, best, bchunk);
-        }
-      }
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) T[r][c] = wave_uniform(sh_T[4 * r + c]);
 
-      // ---- fix-up: exact index inside the winning chunk; moments in float64 ----------------
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int j0 = bchunk[p] * CHUNK;
-        float bd = INFINITY;
-        int bi = j0;
-        float q[DIM] = {};
-#pragma unroll
-        for (int k = 0; k < CHUNK; ++k) {
-          const int j = j0 + k;
-          float bx, by, bz = 0.f;
-          if (resident) {
-            const TP v = tile[j];
-            bx = v.x; by = v.y;
-            if constexpr (DIM == 3) bz = v.z;
-          } else {
-            const bool in = j < m;
-            bx = in ? gtgt[(int64_t)DIM * j] : kFar;
-            by = in ? gtgt[(int64_t)DIM * j + 1] : kFar;
-            if constexpr (DIM == 3) bz = in ? gtgt[(int64_t)DIM * j + 2] : kFar;
-          }
-          float d;
-          if constexpr (DIM == 2) d = dist2(a[p][0], a[p][1], bx, by);
-          else d = dist2(a[p][0], a[p][1], a[p][2], bx, by, bz);
-          if (d < bd || k == 0) {
-            bd = d; bi = j; q[0] = bx; q[1] = by;
-            if constexpr (DIM == 3) q[2] = bz;
-          }
-        }
-        if (live[p]) {
-          double qd[DIM];
-#pragma unroll
-          for (int r = 0; r < DIM; ++r) qd[r] = (double)q[r];
-          acc.add(pd[p], qd, box);
-          if (args.out_corr) args.out_corr[s0 + base + p * blockDim.x + tid] = bi;
-        }
-      }
+    PairAcc<DIM> acc;
+    acc.clear();
+    const int passes = n > 0 ? (n + src_per_pass - 1) / src_per_pass : 1;
+    if (passes == 1) {
+      run_pass(0, T, acc);               // common case: the zeroed accumulators never live across the sweep
+    } else {
+      for (int pass = 0; pass < passes; ++pass) run_pass(pass * src_per_pass, T, acc);
     }
 
     // ---- block reduction → lane 0 solves -------------------------------------------------------

@@ -15,8 +15,10 @@
 
 #if defined(__HIPCC__)
 #define LSLAM_HD __host__ __device__ inline
+#define LSLAM_UNROLL _Pragma("unroll")
 #else
 #define LSLAM_HD inline
+#define LSLAM_UNROLL
 #endif
 
 namespace lslam {
@@ -68,7 +70,9 @@ LSLAM_HD void polar_3d(const double S[9], double R[9]) {
 
   for (int sweep = 0; sweep < 30; ++sweep) {
     double off = 0.0;
+    LSLAM_UNROLL
     for (int p = 0; p < 2; ++p)
+      LSLAM_UNROLL
       for (int q = p + 1; q < 3; ++q) {
         double al = 0.0, be = 0.0, ga = 0.0;
         for (int i = 0; i < 3; ++i) {
@@ -93,16 +97,24 @@ LSLAM_HD void polar_3d(const double S[9], double R[9]) {
       }
     if (off < 1e-15) break;
   }
-  // column norms = singular values; pick the two largest
+  // column norms = singular values; order the columns by descending norm with fixed-index swaps
+  // (no runtime-indexed arrays: those would live in scratch memory on the GPU)
   double sg[3];
   for (int j = 0; j < 3; ++j)
     sg[j] = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
-  int i0 = 0;
-  if (sg[1] > sg[i0]) i0 = 1;
-  if (sg[2] > sg[i0]) i0 = 2;
-  int i1 = (i0 == 0) ? 1 : 0;
-  for (int j = 0; j < 3; ++j)
-    if (j != i0 && sg[j] > sg[i1]) i1 = j;
+#define LSLAM_SWAP_COLS(a, b)                                                         \
+  if (sg[b] > sg[a]) {                                                                \
+    double t_ = sg[a]; sg[a] = sg[b]; sg[b] = t_;                                     \
+    for (int i = 0; i < 3; ++i) {                                                     \
+      t_ = A[3 * i + a]; A[3 * i + a] = A[3 * i + b]; A[3 * i + b] = t_;              \
+      t_ = V[3 * i + a]; V[3 * i + a] = V[3 * i + b]; V[3 * i + b] = t_;              \
+    }                                                                                 \
+  }
+  LSLAM_SWAP_COLS(0, 1)
+  LSLAM_SWAP_COLS(1, 2)
+  LSLAM_SWAP_COLS(0, 1)
+#undef LSLAM_SWAP_COLS
+  constexpr int i0 = 0, i1 = 1;
   double u1[3], u2[3], v1[3], v2[3];
   for (int i = 0; i < 3; ++i) {
     u1[i] = A[3 * i + i0] / sg[i0];
