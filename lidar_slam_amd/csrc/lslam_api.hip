@@ -249,7 +249,8 @@ int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64
   int dev = 0;
   LSLAM_HIP_TRY(hipGetDevice(&dev));
   LargeWs& ws = large_ws();
-  int rc = ws.ensure(dev, n);
+  const NnGeometry geo = nn_geometry(dim, n, m);
+  int rc = ws.ensure(dev, n * geo.splits);
   if (rc != LSLAM_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
 
@@ -259,12 +260,11 @@ int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64
   stop_init(hs->stop);
   hs->done = 0;
   LSLAM_HIP_TRY(hipMemcpyAsync(ws.state, hs, sizeof(LargeState), hipMemcpyHostToDevice, st));
-  LSLAM_HIP_TRY(launch_keys_init(ws.keys, n, st));
 
   NnArgs na{};
   na.src = d_src; na.n = n; na.tgt = d_tgt; na.m = m; na.keys = ws.keys; na.state = ws.state;
   MomArgs ma{};
-  ma.src = d_src; ma.n = n; ma.tgt = d_tgt; ma.keys = ws.keys; ma.state = ws.state; ma.partials = ws.partials;
+  ma.src = d_src; ma.n = n; ma.tgt = d_tgt; ma.keys = ws.keys; ma.splits = geo.splits; ma.state = ws.state; ma.partials = ws.partials;
   ma.out_corr = d_out_corr; ma.flags = flags;
   const int rows = moments_rows(n);
   SolveArgs sa{};
@@ -276,7 +276,7 @@ int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64
   int64_t launched = 0;
   for (;;) {
     for (int k = 0; k < poll_every && launched < cap; ++k, ++launched) {
-      LSLAM_HIP_TRY(launch_nn(na, dim, st));
+      LSLAM_HIP_TRY(launch_nn(na, dim, geo, st));
       LSLAM_HIP_TRY(launch_moments(ma, dim, rows, st));
       LSLAM_HIP_TRY(launch_solve(sa, dim, st));
     }
@@ -302,16 +302,16 @@ int lslam_nn_dev(const float* d_src, int64_t n, const float* d_tgt, int64_t m, i
   int dev = 0;
   LSLAM_HIP_TRY(hipGetDevice(&dev));
   LargeWs& ws = large_ws();
-  int rc = ws.ensure(dev, n);
+  const NnGeometry geo = nn_geometry(dim, n, m);
+  int rc = ws.ensure(dev, n * geo.splits);
   if (rc != LSLAM_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   NnArgs na{};
   na.src = d_src; na.n = n; na.tgt = d_tgt; na.m = m; na.keys = ws.keys; na.state = nullptr;
   static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   memcpy(na.T, T ? T : I4, sizeof(double) * 16);
-  LSLAM_HIP_TRY(launch_keys_init(ws.keys, n, st));
-  LSLAM_HIP_TRY(launch_nn(na, dim, st));
-  LSLAM_HIP_TRY(launch_nn_finalize(ws.keys, n, d_out_idx, d_out_d2, st));
+  LSLAM_HIP_TRY(launch_nn(na, dim, geo, st));
+  LSLAM_HIP_TRY(launch_nn_finalize(ws.keys, n, geo.splits, d_out_idx, d_out_d2, st));
   return LSLAM_OK;
 }
 
@@ -430,6 +430,8 @@ struct Ogm {
   hipStream_t stream = nullptr;
   double* d_scan = nullptr; int64_t scan_cap = 0;     // points
   uint8_t* d_bin = nullptr;
+  OgmScan* d_desc = nullptr; int64_t desc_cap = 0;    // one descriptor per scan of the current call
+  std::vector<OgmScan> h_desc;
 };
 int ogm_scan_buffer(Ogm* o, int64_t points) {
   if (points <= o->scan_cap) return LSLAM_OK;
@@ -460,8 +462,9 @@ int lslam_ogm_create(double res, double world_min_x, double world_min_y, int32_t
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipMalloc(&o->g.logodds, sizeof(float) * cells)) != hipSuccess ||
-      (e = hipMalloc(&o->g.counts, sizeof(int32_t) * cells)) != hipSuccess ||
-      (e = hipMalloc(&o->g.bbox, sizeof(int32_t) * 8)) != hipSuccess ||
+      (e = hipMalloc(&o->g.counts, sizeof(int32_t) * cells * kOgmPlanes)) != hipSuccess ||
+      (e = hipMalloc(&o->g.bbox, sizeof(int32_t) * 8 * kOgmPlanes)) != hipSuccess ||
+
       (e = hipMalloc(&o->d_bin, cells)) != hipSuccess ||
       (e = launch_ogm_init(o->g, o->stream)) != hipSuccess ||
       (e = hipStreamSynchronize(o->stream)) != hipSuccess) {
@@ -482,6 +485,7 @@ int lslam_ogm_destroy(void* handle) {
   if (o->g.bbox) (void)hipFree(o->g.bbox);
   if (o->d_scan) (void)hipFree(o->d_scan);
   if (o->d_bin) (void)hipFree(o->d_bin);
+  if (o->d_desc) (void)hipFree(o->d_desc);
   if (o->stream) (void)hipStreamDestroy(o->stream);
   delete o;
   return LSLAM_OK;
@@ -496,14 +500,35 @@ int lslam_ogm_set_params(void* handle, double logodds_step, double logodds_clip)
   return LSLAM_OK;
 }
 
-static int ogm_enqueue_scan(Ogm* o, const double* pose, const double* d_scan, int32_t n, bool apply) {
-  OgmScan sc{};
-  sc.scan_xy = d_scan; sc.n = n;
-  sc.x = pose[0]; sc.y = pose[1]; sc.c = cos(pose[2]); sc.s = sin(pose[2]);
-  sc.parity = o->parity;
-  LSLAM_HIP_TRY(launch_ogm_raycast(o->g, sc, o->stream));
-  if (apply) LSLAM_HIP_TRY(launch_ogm_apply(o->g, o->parity, o->stream));
-  o->parity ^= 1;
+// Upload one descriptor per scan, then per group of up to kOgmPlanes scans: raycast launch → apply
+// (or nothing) launch.  No host synchronisation inside.
+static int ogm_enqueue(Ogm* o, const double* poses, const double* d_points, const int64_t* scan_off,
+                       int64_t first_point, int32_t K, bool apply) {
+  if (K > o->desc_cap) {
+    if (o->d_desc) (void)hipFree(o->d_desc);
+    o->d_desc = nullptr; o->desc_cap = 0;
+    const int64_t want = K + K / 4 + 64;
+    LSLAM_HIP_TRY(hipMalloc(&o->d_desc, sizeof(OgmScan) * (size_t)want));
+    o->desc_cap = want;
+  }
+  o->h_desc.resize((size_t)K);
+  for (int32_t k = 0; k < K; ++k) {
+    const double* pose = poses + 3 * (size_t)k;
+    OgmScan& h = o->h_desc[(size_t)k];
+    h.scan_xy = d_points + 2 * (scan_off[k] - first_point);
+    h.n = (int32_t)(scan_off[k + 1] - scan_off[k]);
+    h.x = pose[0]; h.y = pose[1]; h.c = cos(pose[2]); h.s = sin(pose[2]);
+    h.pad_ = 0;
+  }
+  if (K > 0) LSLAM_HIP_TRY(hipMemcpyAsync(o->d_desc, o->h_desc.data(), sizeof(OgmScan) * (size_t)K, hipMemcpyHostToDevice, o->stream));
+  for (int32_t k0 = 0; k0 < K; k0 += kOgmPlanes) {
+    const int32_t cnt = (K - k0 < kOgmPlanes) ? (K - k0) : kOgmPlanes;
+    int max_rays = 0;
+    for (int32_t b = 0; b < cnt; ++b) if (o->h_desc[(size_t)(k0 + b)].n > max_rays) max_rays = o->h_desc[(size_t)(k0 + b)].n;
+    LSLAM_HIP_TRY(launch_ogm_raycast(o->g, o->d_desc + k0, cnt, max_rays, o->parity, o->stream));
+    if (apply) LSLAM_HIP_TRY(launch_ogm_apply(o->g, cnt, o->parity, 0, o->stream));
+    o->parity ^= 1;
+  }
   return LSLAM_OK;
 }
 
@@ -523,10 +548,7 @@ int lslam_ogm_update(void* handle, const double* poses, const double* scans_xy, 
     if (!scans_xy) return fail(LSLAM_ERR_BAD_ARG, "null scan pointer");
     LSLAM_HIP_TRY(hipMemcpyAsync(o->d_scan, scans_xy + 2 * first, sizeof(double) * 2 * (size_t)total, hipMemcpyHostToDevice, o->stream));
   }
-  for (int32_t k = 0; k < K; ++k) {
-    const int32_t n = (int32_t)(scan_off[k + 1] - scan_off[k]);
-    if ((rc = ogm_enqueue_scan(o, poses + 3 * (size_t)k, o->d_scan + 2 * (scan_off[k] - first), n, true)) != LSLAM_OK) return rc;
-  }
+  if ((rc = ogm_enqueue(o, poses, o->d_scan, scan_off, first, K, true)) != LSLAM_OK) return rc;
   LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
   return LSLAM_OK;
 }
@@ -541,9 +563,10 @@ int lslam_ogm_scan_counts(void* handle, const double* pose, const double* scan_x
   if ((rc = ogm_scan_buffer(o, n)) != LSLAM_OK) return rc;
   if (n > 0) LSLAM_HIP_TRY(hipMemcpyAsync(o->d_scan, scan_xy, sizeof(double) * 2 * (size_t)n, hipMemcpyHostToDevice, o->stream));
   const int parity = o->parity;
-  if ((rc = ogm_enqueue_scan(o, pose, o->d_scan, n, false)) != LSLAM_OK) return rc;
+  const int64_t off[2] = {0, n};
+  if ((rc = ogm_enqueue(o, pose, o->d_scan, off, 0, 1, false)) != LSLAM_OK) return rc;
   LSLAM_HIP_TRY(hipMemcpyAsync(out_counts, o->g.counts, sizeof(int32_t) * (size_t)o->g.width * o->g.height, hipMemcpyDeviceToHost, o->stream));
-  LSLAM_HIP_TRY(launch_ogm_clear_counts(o->g, parity, o->stream));
+  LSLAM_HIP_TRY(launch_ogm_apply(o->g, 1, parity, 1, o->stream));      // clear only
   LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
   return LSLAM_OK;
 }

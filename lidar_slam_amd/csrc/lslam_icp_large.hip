@@ -5,10 +5,11 @@
 //                     in registers (transformed on load: icp.py:116 fused) and sweeps its share of the
 //                     target through LDS tiles with wave-uniform ds_read_b128 — the same
 //                     distance / v_min3 / (min, chunk) inner loop as the batched kernel.  Per source
-//                     the partial result is merged with atomicMin on a 64-bit key
-//                     (float bits of d² << 32 | index): exact argmin, lowest index on ties.
-//   moments_kernel    gathers the matched targets, accumulates the float64 moments per workgroup,
-//                     resets the keys for the next iteration, optionally writes correspondences.
+//                     the partial result of split s is stored as a 64-bit key
+//                     (float bits of d² << 32 | index) in keys[s][i]; the minimum over s is the exact
+//                     argmin with the lowest index on ties (no atomics, no reset pass).
+//   moments_kernel    reduces the keys over the splits, gathers the matched targets, accumulates the
+//                     float64 moments per workgroup, optionally writes correspondences.
 //   solve_kernel      one wave: fixed-order sum of the partial rows → Kabsch solve → stop rules →
 //                     new T and the `done` flag in device memory.
 // Every kernel returns at once when `done` is set, so the host may enqueue iterations ahead and
@@ -61,9 +62,8 @@ nn_tiled_kernel(NnArgs a) {
   // ---- my share of the target ------------------------------------------------------------------
   // splits are cut on CHUNK boundaries so that chunk ids are global
   const int64_t chunks_total = (a.m + CHUNK - 1) / CHUNK;
-  const int64_t chunks_per_split = (chunks_total + gridDim.y - 1) / gridDim.y;
-  const int64_t c_begin = (int64_t)blockIdx.y * chunks_per_split;
-  const int64_t c_end = min(chunks_total, c_begin + chunks_per_split);
+  const int64_t c_begin = (int64_t)blockIdx.y * a.chunks_per_split;      // whole tiles per split
+  const int64_t c_end = min(chunks_total, c_begin + a.chunks_per_split);
 
   float best[P];
   int bchunk[P];
@@ -132,9 +132,17 @@ nn_tiled_kernel(NnArgs a) {
       }
     }
   }
-  if (c_begin >= c_end) return;
+  unsigned long long* __restrict__ keys = a.keys + (int64_t)blockIdx.y * a.n;   // this split's row
+  if (c_begin >= c_end) {                                   // empty split: neutral keys
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int64_t i = base + (int64_t)p * kNnThreads + tid;
+      if (i < a.n) keys[i] = kKeyInit;
+    }
+    return;
+  }
 
-  // ---- fix-up from global memory (the winning chunk may have left LDS) + merge ------------------
+  // ---- fix-up from global memory (the winning chunk may have left LDS) + store -------------------
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int64_t i = base + (int64_t)p * kNnThreads + tid;
@@ -157,24 +165,27 @@ nn_tiled_kernel(NnArgs a) {
       }
       if (d < bd || k == 0) { bd = d; bi = j; }
     }
-    const unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(uint32_t)bi;
-    atomicMin(a.keys + i, key);
+    keys[i] = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(uint32_t)bi;
   }
 }
 
-// keys → (index, d²), keys reset.  Used by the NN-only entry point.
-__global__ void nn_finalize_kernel(unsigned long long* keys, int64_t n, int32_t* out_idx, float* out_d2) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long k = keys[i];
-  if (out_idx) out_idx[i] = (int32_t)(uint32_t)(k & 0xffffffffull);
-  if (out_d2) out_d2[i] = __uint_as_float((uint32_t)(k >> 32));
-  keys[i] = kKeyInit;
+// min over the split rows of the keys (exact argmin, lowest index on ties)
+__device__ __forceinline__ unsigned long long reduce_keys(const unsigned long long* keys, int64_t n, int splits, int64_t i) {
+  unsigned long long k = keys[i];
+  for (int s = 1; s < splits; ++s) {
+    const unsigned long long v = keys[(int64_t)s * n + i];
+    k = v < k ? v : k;
+  }
+  return k;
 }
 
-__global__ void keys_init_kernel(unsigned long long* keys, int64_t n) {
+// keys → (index, d²).  Used by the NN-only entry point.
+__global__ void nn_finalize_kernel(const unsigned long long* keys, int64_t n, int splits, int32_t* out_idx, float* out_d2) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) keys[i] = kKeyInit;
+  if (i >= n) return;
+  const unsigned long long k = reduce_keys(keys, n, splits, i);
+  if (out_idx) out_idx[i] = (int32_t)(uint32_t)(k & 0xffffffffull);
+  if (out_d2) out_d2[i] = __uint_as_float((uint32_t)(k >> 32));
 }
 
 // ---- moments -------------------------------------------------------------------------------------
@@ -194,8 +205,7 @@ moments_kernel(MomArgs a) {
   PairAcc<DIM> acc;
   acc.clear();
   for (int64_t i = (int64_t)blockIdx.x * kMomThreads + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kMomThreads) {
-    const uint32_t j = (uint32_t)(a.keys[i] & 0xffffffffull);
-    a.keys[i] = kKeyInit;
+    const uint32_t j = (uint32_t)(reduce_keys(a.keys, a.n, a.splits, i) & 0xffffffffull);
     if (a.out_corr) a.out_corr[i] = (int32_t)j;
     double x = a.src[DIM * i], y = a.src[DIM * i + 1], z = 0.0;
     if constexpr (DIM == 3) z = a.src[DIM * i + 2];
@@ -264,48 +274,54 @@ solve_kernel(SolveArgs a) {
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
-void nn_geometry(int dim, int64_t n, int64_t m, int* P, dim3* grid, int* tile_points, size_t* smem) {
+NnGeometry nn_geometry(int dim, int64_t n, int64_t m) {
+  NnGeometry g{};
   const int CHUNK = (dim == 2) ? IcpChunk<2>::value : IcpChunk<3>::value;
-  *P = (n >= 4 * 256 * kNnThreads) ? 4 : 2;
-  const int64_t per_block = (int64_t)kNnThreads * (*P);
+  const int pt_bytes = (dim == 2) ? 8 : 16;
+  g.P = (n >= 65536) ? 4 : (n >= 8192 ? 2 : 1);
+  const int64_t per_block = (int64_t)kNnThreads * g.P;
   const int64_t sb = (n + per_block - 1) / per_block;
-  const int64_t chunks = (m + CHUNK - 1) / CHUNK;
-  // enough workgroups to fill 256 CUs a few times over, but never a split smaller than one tile
-  int64_t splits = (4 * 256 + sb - 1) / sb;
-  const int tile = (dim == 2) ? kNnTilePlanar : kNnTile3D;
-  const int64_t max_splits = (chunks * CHUNK + tile - 1) / tile;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  if (splits > 65535) splits = 65535;
-  *grid = dim3((unsigned)sb, (unsigned)splits);
-  *tile_points = tile;
-  *smem = (size_t)tile * ((dim == 2) ? 8 : 16);
+  // Aim at ~8 workgroups per CU so that the last partial round of workgroups is short; a split is
+  // a whole number of LDS tiles, a tile at least kNnTileMin points.
+  int64_t want = (kNnTargetWorkgroups + sb - 1) / sb;
+  if (want < 1) want = 1;
+  if (want > kNnMaxSplits) want = kNnMaxSplits;
+  const int tile_max = (dim == 2) ? kNnTilePlanar : kNnTile3D;
+  int64_t tile = ((m + want - 1) / want + CHUNK - 1) / CHUNK * CHUNK;
+  if (tile < kNnTileMin) tile = kNnTileMin;
+  if (tile > tile_max) tile = tile_max;
+  const int64_t tiles_total = (m + tile - 1) / tile;
+  int64_t tiles_per_split = tiles_total / want;
+  if (tiles_per_split < 1) tiles_per_split = 1;
+  const int64_t splits = (tiles_total + tiles_per_split - 1) / tiles_per_split;
+  g.grid_x = (unsigned)sb;
+  g.splits = (int)splits;
+  g.tile_points = (int)tile;
+  g.chunks_per_split = tiles_per_split * (tile / CHUNK);
+  g.smem = (size_t)tile * pt_bytes;
+  return g;
 }
 
-hipError_t launch_nn(NnArgs a, int dim, hipStream_t stream) {
-  int P; dim3 grid; int tile; size_t smem;
-  nn_geometry(dim, a.n, a.m, &P, &grid, &tile, &smem);
-  a.tile_points = tile;
+hipError_t launch_nn(NnArgs a, int dim, const NnGeometry& g, hipStream_t stream) {
+  a.tile_points = g.tile_points;
+  a.chunks_per_split = g.chunks_per_split;
   if (a.n <= 0) return hipSuccess;
+  const dim3 grid(g.grid_x, (unsigned)g.splits), block(kNnThreads);
   if (dim == 2) {
-    if (P == 2) hipLaunchKernelGGL((nn_tiled_kernel<2, 2>), grid, dim3(kNnThreads), smem, stream, a);
-    else hipLaunchKernelGGL((nn_tiled_kernel<2, 4>), grid, dim3(kNnThreads), smem, stream, a);
+    if (g.P == 1) hipLaunchKernelGGL((nn_tiled_kernel<2, 1>), grid, block, g.smem, stream, a);
+    else if (g.P == 2) hipLaunchKernelGGL((nn_tiled_kernel<2, 2>), grid, block, g.smem, stream, a);
+    else hipLaunchKernelGGL((nn_tiled_kernel<2, 4>), grid, block, g.smem, stream, a);
   } else {
-    if (P == 2) hipLaunchKernelGGL((nn_tiled_kernel<3, 2>), grid, dim3(kNnThreads), smem, stream, a);
-    else hipLaunchKernelGGL((nn_tiled_kernel<3, 4>), grid, dim3(kNnThreads), smem, stream, a);
+    if (g.P == 1) hipLaunchKernelGGL((nn_tiled_kernel<3, 1>), grid, block, g.smem, stream, a);
+    else if (g.P == 2) hipLaunchKernelGGL((nn_tiled_kernel<3, 2>), grid, block, g.smem, stream, a);
+    else hipLaunchKernelGGL((nn_tiled_kernel<3, 4>), grid, block, g.smem, stream, a);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_keys_init(unsigned long long* keys, int64_t n, hipStream_t stream) {
+hipError_t launch_nn_finalize(const unsigned long long* keys, int64_t n, int splits, int32_t* out_idx, float* out_d2, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(keys_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, keys, n);
-  return hipGetLastError();
-}
-
-hipError_t launch_nn_finalize(unsigned long long* keys, int64_t n, int32_t* out_idx, float* out_d2, hipStream_t stream) {
-  if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(nn_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, keys, n, out_idx, out_d2);
+  hipLaunchKernelGGL(nn_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, keys, n, splits, out_idx, out_d2);
   return hipGetLastError();
 }
 

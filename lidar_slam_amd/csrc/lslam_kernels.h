@@ -49,6 +49,9 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
 constexpr int kNnThreads = 256;
 constexpr int kNnTilePlanar = 4096;   // 32 KiB of LDS per workgroup → 4 workgroups per CU
 constexpr int kNnTile3D = 2048;       // 32 KiB
+constexpr int kNnTileMin = 128;       // smallest tile worth a workgroup (small clouds: more splits)
+constexpr int kNnTargetWorkgroups = 2048;
+constexpr int kNnMaxSplits = 64;
 constexpr int kMomThreads = 256;
 constexpr int kMomMaxBlocks = 1024;
 
@@ -62,16 +65,27 @@ struct LargeState {          // lives in device memory for the whole run of one 
 struct NnArgs {
   const float* src; int64_t n;
   const float* tgt; int64_t m;
-  unsigned long long* keys;      // n packed (d² bits << 32 | index), pre-set to ~0
+  unsigned long long* keys;      // splits x n packed (d² bits << 32 | index); row s written by split s
   const LargeState* state;       // transform + done flag, or nullptr → use T below
   double T[16];
   int32_t tile_points;           // filled by the launcher
+  int64_t chunks_per_split;      // filled by the launcher
+};
+
+struct NnGeometry {
+  int P;                         // source points per lane
+  unsigned grid_x;               // source blocks
+  int splits;                    // target splits = grid.y = rows of `keys`
+  int tile_points;
+  int64_t chunks_per_split;
+  size_t smem;
 };
 
 struct MomArgs {
   const float* src; int64_t n;
   const float* tgt;
-  unsigned long long* keys;
+  const unsigned long long* keys;
+  int32_t splits;
   const LargeState* state;
   double* partials;              // rows x AccLayout<DIM>::kTotal
   int32_t* out_corr;             // or nullptr
@@ -87,9 +101,9 @@ struct SolveArgs {
   int32_t max_iters;
 };
 
-hipError_t launch_nn(NnArgs a, int dim, hipStream_t stream);
-hipError_t launch_keys_init(unsigned long long* keys, int64_t n, hipStream_t stream);
-hipError_t launch_nn_finalize(unsigned long long* keys, int64_t n, int32_t* out_idx, float* out_d2, hipStream_t stream);
+NnGeometry nn_geometry(int dim, int64_t n, int64_t m);
+hipError_t launch_nn(NnArgs a, int dim, const NnGeometry& g, hipStream_t stream);
+hipError_t launch_nn_finalize(const unsigned long long* keys, int64_t n, int splits, int32_t* out_idx, float* out_d2, hipStream_t stream);
 int moments_rows(int64_t n);
 hipError_t launch_moments(MomArgs a, int dim, int rows, hipStream_t stream);
 hipError_t launch_solve(SolveArgs a, int dim, hipStream_t stream);
@@ -107,23 +121,24 @@ struct PairOpArgs {
 hipError_t launch_pair_op(const PairOpArgs& a, hipStream_t stream);
 
 // ---- occupancy grid (lslam_ogm.hip) -----------------------------------------------------------------
+constexpr int kOgmPlanes = 32;   // scans traced per launch, each into its own int32 count plane
+
 struct OgmGrid {
   float* logodds;          // width*height, [x][y]
-  int32_t* counts;         // width*height scratch, zero between scans
-  int32_t* bbox;           // 2 x {min_x, min_y, max_x, max_y}
+  int32_t* counts;         // kOgmPlanes planes of width*height hit-miss counts, zero between groups
+  int32_t* bbox;           // 2 parities x kOgmPlanes x {min_x, min_y, max_x, max_y}
   int32_t width, height;
   double res, min_x, min_y;
   double step, clip;
 };
 struct OgmScan {
   const double* scan_xy;   // device, n x 2
-  int32_t n;
   double x, y, c, s;       // pose, cos/sin of yaw
-  int32_t parity;          // which bbox slot this scan uses
+  int32_t n;
+  int32_t pad_;
 };
-hipError_t launch_ogm_raycast(const OgmGrid& g, const OgmScan& sc, hipStream_t stream);
-hipError_t launch_ogm_apply(const OgmGrid& g, int parity, hipStream_t stream);
-hipError_t launch_ogm_clear_counts(const OgmGrid& g, int parity, hipStream_t stream);
+hipError_t launch_ogm_raycast(const OgmGrid& g, const OgmScan* d_scans, int nscans, int max_rays, int parity, hipStream_t stream);
+hipError_t launch_ogm_apply(const OgmGrid& g, int nscans, int parity, int clear_only, hipStream_t stream);
 hipError_t launch_ogm_binarize(const OgmGrid& g, uint8_t* out, hipStream_t stream);
 hipError_t launch_ogm_init(const OgmGrid& g, hipStream_t stream);
 

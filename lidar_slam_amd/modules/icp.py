@@ -18,8 +18,8 @@ from .._lib import check, lib, ptr
 from ..batch import icp_batch
 
 # one workgroup iterates a pair on chip; beyond this many pair evaluations per iteration the
-# whole-chip path (grid-wide LDS-tiled search, three launches per iteration) is faster
-LARGE_PAIR_EVALS = 4_000_000
+# whole-chip path (grid-wide LDS-tiled search, three launches ≈ 10 µs per iteration) is faster
+LARGE_PAIR_EVALS = 300_000
 
 _DEVICE = 0
 
