@@ -48,13 +48,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5"])
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5", "ogm"])
     ap.add_argument("--pairs", type=int, default=4096, help="scan pairs per GPU (c4)")
     ap.add_argument("--points", type=int, default=4096, help="points per cloud (c4)")
     ap.add_argument("--iters", type=int, default=50, help="forced ICP iterations per pair (c4/c2/c5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=96)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=256)
     return ap.parse_args()
 
 
@@ -212,7 +212,7 @@ def main():
         result = other_config(a.workload, a, torch, device, stream, timed=True)
 
     if rank == 0 and world == 1 and a.workload == "c4" and not a.no_other_configs:
-        result["other_configs"] = {k: other_config(k, a, torch, device, stream, timed=False) for k in ("c2", "c3", "c5")}
+        result["other_configs"] = {k: other_config(k, a, torch, device, stream, timed=False) for k in ("c2", "c3", "c5", "ogm")}
 
     if rank == 0:
         print(json.dumps(result))
@@ -220,11 +220,51 @@ def main():
         dist.destroy_process_group()
 
 
+_SEQ = {}
+
+
+def _sequence():
+    """the dataset-20-like synthetic sequence, generated once per process"""
+    from lidar_slam_amd import synth
+    if "seq" not in _SEQ:
+        t0 = time.perf_counter()
+        _SEQ["seq"] = synth.sequence_c3(4956, seed=20)
+        _SEQ["gen_s"] = time.perf_counter() - t0
+    return _SEQ["seq"], _SEQ["gen_s"]
+
+
 def other_config(name, a, torch, device, stream, timed):
     """one-shot timings of the other BASELINE configs (not the headline line)"""
     from lidar_slam_amd import batch as B
     from lidar_slam_amd import synth
     out = {}
+    if name == "ogm":
+        from lidar_slam_amd.modules.ogm import OccupancyGridMap
+        from oracle.ogm_oracle import OccupancyGridOracle
+        seq, _ = _sequence()
+        OccupancyGridMap(0.05, 30, 30, -30, -30).build_map(seq.true_poses[:64], seq.z_ts[:64])      # warm-up
+        g = OccupancyGridMap(0.05, 30, 30, -30, -30)                                               # main.py --res 0.05 --width 60 --height 60
+        t0 = time.perf_counter()
+        g.build_map(seq.true_poses, seq.z_ts)
+        dt = time.perf_counter() - t0
+        rays = int(sum(z.shape[0] for z in seq.z_ts))
+        k = 16                                          # bounded CPU sample: the oracle's per-ray loop (ogm.py:172-185 restated)
+        o = OccupancyGridOracle(0.05, 30, 30, -30, -30)
+        t0 = time.perf_counter()
+        cells = 0
+        for i in range(k):
+            c = o.scan_counts(seq.true_poses[i], seq.z_ts[i])
+            cells += int(np.abs(c).sum())
+            o.apply_counts(c)
+        cpu_s = (time.perf_counter() - t0) / k
+        g2 = OccupancyGridMap(0.05, 30, 30, -30, -30)
+        g2.build_map(seq.true_poses[:k], seq.z_ts[:k])
+        return {"workload": "OGM build_map: 4956 scans of the C3 sequence into a 1201x1201 grid (res 0.05), host arrays in (PCIe included)",
+                "seconds": dt, "scans_per_sec": len(seq.z_ts) / dt, "rays_per_sec": rays / dt,
+                "cell_updates_per_sec": cells / k * len(seq.z_ts) / dt, "cell_updates_per_scan": cells / k,
+                "cpu_port_seconds_per_scan": cpu_s, "cpu_port_extrapolated_seconds": cpu_s * len(seq.z_ts),
+                "speedup_vs_cpu_port_1core": cpu_s * len(seq.z_ts) / dt,
+                "logodds_equal_to_oracle_on_sample": bool(np.array_equal(g2.grid_map_log_odds, o.grid_map_log_odds))}
     if name == "c2":
         src, tgt, T_true = synth.pair_c2(0)
         s = torch.from_numpy(src.astype(np.float32)).to(device); t = torch.from_numpy(tgt.astype(np.float32)).to(device)
@@ -260,9 +300,7 @@ def other_config(name, a, torch, device, stream, timed):
                "valu_tflops_alg": it * 1e10 * 8 / (ms * 1e-3) / 1e12, "pose_err_vs_truth": float(np.abs(T - T_true).max())}
     elif name == "c3":
         from lidar_slam_amd.modules.localization import scan_matching_relative_poses, chain_poses
-        t0 = time.perf_counter()
-        seq = synth.sequence_c3(4956, seed=20)
-        gen_s = time.perf_counter() - t0
+        seq, gen_s = _sequence()
         scan_matching_relative_poses(seq.x_ts[:64], seq.z_ts[:64])                     # warm-up
         t0 = time.perf_counter()
         rel, info = scan_matching_relative_poses(seq.x_ts, seq.z_ts, return_info=True)

@@ -60,6 +60,49 @@ def scan_matching_relative_poses(x_ts, z_ts, device=0, return_info=False):
     return (rel, r) if return_info else rel
 
 
+def loop_closure_constraints(z_ts, n_poses=None, fixed_interval=10, max_distance=np.inf, max_yaw=np.inf,
+                             device=0):
+    """The loop-closure ICP problems of ``--mode gtsam`` (main.py:158-172) as ONE batched launch.
+
+    For i = 0, K, 2K, … < n_poses − K: ``run_icp(z_ts[i], z_ts[i+K], return_error=True,
+    normalize_error=True)`` — identity initial guess, default epsilon 0.01 — then the reference's
+    gate ``translation < max_distance and rad2deg(angle) < max_yaw`` (main.py:167; the reference
+    takes both limits from the odometry, main.py:100-101).
+
+    Returns (pairs (L,2) int, T_se2 (L,3,3), errors (L,), accepted (L,) bool): every tested pair
+    with its relative SE(2) transform and normalised error; ``accepted`` marks the ones the
+    reference would add to the factor graph as BetweenFactorPose2(i, i+K, pose_from_T(T))."""
+    n_poses = len(z_ts) if n_poses is None else int(n_poses)
+    K = int(fixed_interval)
+    starts = np.arange(0, n_poses - K, K, dtype=np.int64)
+    if starts.size == 0:
+        return np.zeros((0, 2), np.int64), np.zeros((0, 3, 3)), np.zeros(0), np.zeros(0, bool)
+    src, so = pack_clouds([np.asarray(z_ts[i]) for i in starts])
+    tgt, to = pack_clouds([np.asarray(z_ts[i + K]) for i in starts])
+    r = icp_batch(src, so, tgt, to, np.tile(np.eye(4), (starts.size, 1, 1)), normalize_error=True, device=device)
+    T3 = np.tile(np.eye(3), (starts.size, 1, 1))
+    T3[:, :2, :2] = r.T[:, :2, :2]
+    T3[:, :2, 2] = r.T[:, :2, 3]
+    angle = np.arctan2(T3[:, 1, 0], T3[:, 0, 0])
+    translation = np.linalg.norm(T3[:, :2, 2], axis=1)
+    accepted = (translation < max_distance) & (np.rad2deg(angle) < max_yaw)
+    return np.column_stack((starts, starts + K)), T3, r.error, accepted
+
+
+def save_scan_matching_outputs(poses, relative_poses, dataset_num, out_dir="outputs"):
+    """The two files ``--mode scan_matching`` leaves behind (main.py:123-124; consumed by
+    plot_trajectories.py:13): ``poses_scan_matching_<ds>.npy`` (N,3) and
+    ``relative_poses_scan_matching_<ds>.npy`` (N-1,3,3), float64."""
+    import os
+    os.makedirs(out_dir, exist_ok=True)
+    paths = (os.path.join(out_dir, f"poses_scan_matching_{dataset_num}.npy"),
+             os.path.join(out_dir, f"relative_poses_scan_matching_{dataset_num}.npy"))
+    for path, arr in zip(paths, (poses, relative_poses)):
+        with open(path, "wb") as f:
+            np.save(f, np.asarray(arr, dtype=np.float64))
+    return paths
+
+
 def poses_from_scan_matching(x_ts, z_ts, return_relative_poses=False):
     """Refine the odometry trajectory by frame-to-frame scan matching
     (modules/localization.py:95-134): same arguments, same returns —

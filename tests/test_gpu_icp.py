@@ -249,3 +249,77 @@ def test_dense_3d_nn_against_exact_c_oracle(icp):
     ref_idx, ref_d2 = c_oracle.nn_f32(src, tgt)
     np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx)
     np.testing.assert_array_equal(d2.cpu().numpy(), ref_d2)
+
+
+def _random_problem(rng, dim, n, m, spread):
+    tgt = rng.normal(size=(m, dim)) * spread
+    th = rng.uniform(-0.2, 0.2)
+    R = np.eye(dim)
+    R[:2, :2] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]
+    pick = rng.integers(0, m, n)
+    src = (tgt[pick] - rng.normal(0, 0.05 * spread, dim)) @ R + rng.normal(0, 0.01 * spread, (n, dim))
+    return src, tgt
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_ragged_random_batch_matches_exact_oracle(icp, dim):
+    """ragged sizes from 5 points to a few thousand (rank-deficient toy cases are parity-undefined in the reference), duplicates included: identical iteration
+    counts and correspondences as the C oracle's device recipe (exact fmaf), T to 1e-9"""
+    from lidar_slam_amd.batch import icp_batch, pack_clouds
+    from oracle import c_oracle
+    rng = np.random.default_rng(100 + dim)
+    sizes = [(8, 6), (5, 1500), (17, 16), (64, 65), (65, 64), (200, 33), (1000, 999), (1081, 1081), (2500, 700), (513, 4100)]
+    srcs, tgts = [], []
+    for n, m in sizes:
+        s, t = _random_problem(rng, dim, n, m, spread=rng.uniform(0.5, 20.0))
+        if m > 40:
+            t[m // 2] = t[3]                          # an exact duplicate target: lowest index must win
+        srcs.append(s); tgts.append(t)
+    fs, so = pack_clouds(srcs)
+    ft, to = pack_clouds(tgts)
+    init = np.tile(np.eye(4), (len(sizes), 1, 1))
+    r = icp_batch(fs, so, ft, to, init, epsilon=1e-12, max_iters=25, return_correspondences=True)
+    for k, (s, t) in enumerate(zip(srcs, tgts)):
+        To, eo, co, ito = c_oracle.run_icp(s, t, np.eye(4), epsilon=1e-12, max_iters=25, recipe="device")
+        assert r.iterations[k] == ito, (k, sizes[k])
+        np.testing.assert_array_equal(r.correspondences[so[k]:so[k + 1]], co, err_msg=str(sizes[k]))
+        np.testing.assert_allclose(r.T[k], To, atol=1e-9, err_msg=str(sizes[k]))
+        np.testing.assert_allclose(r.error[k], eo, rtol=1e-9, atol=1e-18)
+
+
+@pytest.mark.parametrize("dim,n,m", [(2, 700, 5000), (3, 9000, 3000), (2, 70000, 1200), (3, 300, 40000)])
+def test_whole_chip_path_random_shapes_match_exact_oracle(icp, dim, n, m):
+    """the three-launch path over its geometry regimes (P = 1/2/4, one and many splits)"""
+    from lidar_slam_amd import _lib
+    from lidar_slam_amd._lib import check, lib, ptr
+    from oracle import c_oracle
+    rng = np.random.default_rng(n + m)
+    s, t = _random_problem(rng, dim, n, m, spread=3.0)
+    s32, t32 = np.ascontiguousarray(s, np.float32), np.ascontiguousarray(t, np.float32)
+    T = np.empty((4, 4)); err = np.empty(1); it = np.empty(1, np.int32); corr = np.empty(n, np.int32)
+    T0 = np.eye(4)
+    check(lib().lslam_icp_large(ptr(s32), n, ptr(t32), m, dim, ptr(T0), 1e-12, 1e-4, 6, 0, ptr(T), ptr(err), ptr(it), ptr(corr), 0))
+    To, eo, co, ito = c_oracle.run_icp(s, t, np.eye(4), epsilon=1e-12, max_iters=6, recipe="device")
+    assert it[0] == ito
+    np.testing.assert_array_equal(corr, co)
+    np.testing.assert_allclose(T, To, atol=1e-9)
+    np.testing.assert_allclose(err[0], eo, rtol=1e-9)
+
+
+def test_loop_closure_batch_matches_per_pair_reference_semantics(icp, tmp_path):
+    """main.py:158-172 as one launch: source = scan i, target = scan i+K, identity init,
+    normalize_error=True, default epsilon; gating and file outputs keep the reference's shapes"""
+    from lidar_slam_amd.modules.localization import loop_closure_constraints, save_scan_matching_outputs
+    from oracle import icp_oracle
+    g = golden("seq_scanmatch.npz")
+    z = split(g["z"], g["z_off"])
+    pairs, T3, errors, ok = loop_closure_constraints(z, fixed_interval=10, max_distance=0.25, max_yaw=2.0)
+    assert pairs.tolist() == [[0, 10], [10, 20], [20, 30]]
+    for (i, j), T, e in zip(pairs, T3, errors):
+        o = icp_oracle.run_icp_full(z[i], z[j], None, normalize_error=True)          # float64 reference semantics
+        assert np.abs(T[:2, 2] - o.T[:2, 3]).max() < TOL_TRANS and np.abs(T[:2, :2] - o.T[:2, :2]).max() < TOL_ROT
+        assert abs(e - o.error) < 1e-6 * o.error + 1e-12
+        ang = np.rad2deg(np.arctan2(T[1, 0], T[0, 0]))
+        assert ok[list(pairs[:, 0]).index(i)] == (np.linalg.norm(T[:2, 2]) < 0.25 and ang < 2.0)
+    paths = save_scan_matching_outputs(g["poses"], g["relative_poses"], 20, out_dir=str(tmp_path))
+    assert np.load(paths[0]).shape == (32, 3) and np.load(paths[1]).shape == (31, 3, 3)
