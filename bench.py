@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5", "ogm"])
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5", "ogm", "filter_lidar"])
     ap.add_argument("--pairs", type=int, default=4096, help="scan pairs per GPU (c4)")
     ap.add_argument("--points", type=int, default=4096, help="points per cloud (c4)")
     ap.add_argument("--iters", type=int, default=50, help="forced ICP iterations per pair (c4/c2/c5)")
@@ -212,7 +212,7 @@ def main():
         result = other_config(a.workload, a, torch, device, stream, timed=True)
 
     if rank == 0 and world == 1 and a.workload == "c4" and not a.no_other_configs:
-        result["other_configs"] = {k: other_config(k, a, torch, device, stream, timed=False) for k in ("c2", "c3", "c5", "ogm")}
+        result["other_configs"] = {k: other_config(k, a, torch, device, stream, timed=False) for k in ("c2", "c3", "c5", "ogm", "filter_lidar")}
 
     if rank == 0:
         print(json.dumps(result))
@@ -238,6 +238,39 @@ def other_config(name, a, torch, device, stream, timed):
     from lidar_slam_amd import batch as B
     from lidar_slam_amd import synth
     out = {}
+    if name == "filter_lidar":
+        # main.py --mode scan_matching --filter_lidar, stages main.py:84-87 + 120: ranges → points → DBSCAN →
+        # radial filter → scan matching, all through the library (host arrays in, poses out)
+        from lidar_slam_amd.modules import localization as L
+        # a small flat (±4.5 m): DBSCAN(0.1, 10) only keeps surfaces closer than ≈4 m (beam spacing < 2 cm),
+        # as in the reference's real scan where 707 of 1076 points survive
+        seq = synth.sequence_c3(4956, seed=21, drop=(0.0, 0.05), half=4.5, n_obstacles=6)
+        L.preprocess_lidar(seq.ranges[:64], 0.1, 30.0, dbscan=(0.1, 10), k_std=2)                  # warm-up
+        t0 = time.perf_counter()
+        z = L.preprocess_lidar(seq.ranges, 0.1, 30.0, dbscan=(0.1, 10), k_std=2)
+        t_pre = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        poses, rel = L.poses_from_scan_matching(seq.x_ts, z, return_relative_poses=True)
+        t_icp = time.perf_counter() - t0
+        # CPU side on a bounded sample: sklearn DBSCAN exactly as the reference calls it + the oracle ICP port
+        from sklearn.cluster import DBSCAN
+        from oracle import preprocess_oracle, se2_oracle
+        n = 200
+        z0 = preprocess_oracle.lidar_xy(seq.ranges[:n + 1], 0.1, 30.0)
+        t0 = time.perf_counter()
+        z1 = [p[DBSCAN(eps=0.1, min_samples=10).fit_predict(p) != -1] for p in z0]
+        cpu_db = (time.perf_counter() - t0) / (n + 1)
+        z2 = preprocess_oracle.statistical_outliers_removal(z1, 2)
+        t0 = time.perf_counter()
+        se2_oracle.poses_from_scan_matching(seq.x_ts[:n + 1], z2)
+        cpu_icp = (time.perf_counter() - t0) / n
+        cpu_total = (cpu_db + cpu_icp) * 4955
+        pts = int(sum(a.shape[0] for a in z))
+        return {"min_points_per_scan": int(min(a.shape[0] for a in z)),
+                "workload": "scan_matching --filter_lidar on synthetic ranges (4956 x 1081, 9 m flat): get_lidar_data + DBSCAN(0.1,10) + radial(k=2) + 4955 ICP pairs + chain, host arrays in/out",
+                "preprocess_seconds": t_pre, "scan_matching_seconds": t_icp, "total_seconds": t_pre + t_icp,
+                "points_after_filters": pts, "cpu_dbscan_seconds_per_scan_sklearn": cpu_db, "cpu_icp_seconds_per_pair_port": cpu_icp,
+                "cpu_extrapolated_seconds_1core": cpu_total, "speedup_vs_cpu_1core": cpu_total / (t_pre + t_icp)}
     if name == "ogm":
         from lidar_slam_amd.modules.ogm import OccupancyGridMap
         from oracle.ogm_oracle import OccupancyGridOracle

@@ -142,6 +142,32 @@ int lslam_kabsch(const double *p, int64_t p_stride, const double *q, int64_t q_s
 int lslam_sq_error(const double *p, const double *q, int64_t n, int32_t cols,
                    int32_t normalize, double *out_err, int device);
 
+/* ---- LiDAR pre-processing: modules/localization.py:201-307 (main.py:84-87) ---------- */
+/*
+ * The chain in front of the ICP path, kept on the device between its stages:
+ *   stage LSLAM_PRE_POLAR   get_lidar_data (localization.py:252-307): ranges (K x B float64) ->
+ *                           robot-frame points; beams with range outside [range_min, range_max] are
+ *                           dropped; x = r*cos_a[b] + off_x, y = r*sin_a[b] + off_y (the caller passes
+ *                           the beam-angle cos/sin table, B float64 each, and the lidar offset).
+ *   stage LSLAM_PRE_DBSCAN  DBSCAN_outliers_removal (localization.py:201-221): drops the points
+ *                           sklearn's DBSCAN(eps, min_samples) labels -1.
+ *   stage LSLAM_PRE_RADIAL  statistical_outliers_removal (localization.py:223-250): drops points whose
+ *                           range is >= mean + k_std*std of the ranges of ALL (remaining) points.
+ * Input: `ranges` when LSLAM_PRE_POLAR is set, else the CSR point set (in_xy, in_off).  Output: CSR
+ * (out_xy capacity = number of input points, out_off K+1), point and scan order preserved.
+ * out_stats (3 float64: mean, std, threshold of the radial stage) may be NULL.  HOST pointers.
+ */
+#define LSLAM_PRE_POLAR  1u
+#define LSLAM_PRE_DBSCAN 2u
+#define LSLAM_PRE_RADIAL 4u
+int lslam_lidar_preprocess(uint32_t stages,
+                           const double *ranges, int32_t K, int32_t B,
+                           const double *cos_a, const double *sin_a, double off_x, double off_y,
+                           double range_min, double range_max,
+                           const double *in_xy, const int64_t *in_off,
+                           double eps, int32_t min_samples, double k_std,
+                           double *out_xy, int64_t *out_off, double *out_stats, int device);
+
 /* ---- occupancy grid: modules/ogm.py ------------------------------------- */
 /* OccupancyGridMap state (ogm.py:37-43) resident in HBM: float32 log-odds
  * (width x height, indexed [x_cell][y_cell], ogm.py:41) plus an int32 hit/miss

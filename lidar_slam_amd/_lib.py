@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "liblslam_hip.so")
 
 OK, ERR_BAD_ARG, ERR_EMPTY_TARGET, ERR_NONFINITE, ERR_HIP = 0, -1, -2, -3, -4
 ICP_NORMALIZE_ERROR = 1
+PRE_POLAR, PRE_DBSCAN, PRE_RADIAL = 1, 2, 4
 
 
 class LslamError(RuntimeError):
@@ -49,6 +50,9 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "lslam_kabsch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int]),
     "lslam_sq_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int]),
+    "lslam_lidar_preprocess": (C.c_int, [C.c_uint32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
+                                         C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_double,
+                                         C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "lslam_ogm_create": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double,
                                    C.c_double, C.c_int, C.POINTER(C.c_void_p)]),
     "lslam_ogm_destroy": (C.c_int, [C.c_void_p]),

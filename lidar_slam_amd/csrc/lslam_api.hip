@@ -421,6 +421,92 @@ int lslam_sq_error(const double* p, const double* q, int64_t n, int32_t cols, in
 }
 
 // ---------------------------------------------------------------------------------------------------
+int lslam_lidar_preprocess(uint32_t stages, const double* ranges, int32_t K, int32_t B, const double* cos_a,
+                           const double* sin_a, double off_x, double off_y, double range_min, double range_max,
+                           const double* in_xy, const int64_t* in_off, double eps, int32_t min_samples, double k_std,
+                           double* out_xy, int64_t* out_off, double* out_stats, int device) {
+  clear_error();
+  if (K < 0) return fail(LSLAM_ERR_BAD_ARG, "negative scan count");
+  if (!out_off) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (!(stages & (LSLAM_PRE_POLAR | LSLAM_PRE_DBSCAN | LSLAM_PRE_RADIAL))) return fail(LSLAM_ERR_BAD_ARG, "no stage selected");
+  const bool polar = (stages & LSLAM_PRE_POLAR) != 0;
+  int64_t total = 0, max_n = 0;
+  if (polar) {
+    if (B <= 0 || !ranges || !cos_a || !sin_a) return fail(LSLAM_ERR_BAD_ARG, "polar stage needs ranges, cos_a, sin_a and B > 0");
+    total = (int64_t)K * B;
+    max_n = B;
+  } else {
+    if (!in_off) return fail(LSLAM_ERR_BAD_ARG, "null input offsets");
+    if (in_off[0] != 0) return fail(LSLAM_ERR_BAD_ARG, "in_off must start at 0");
+    for (int32_t k = 0; k < K; ++k) {
+      const int64_t n = in_off[k + 1] - in_off[k];
+      if (n < 0 || n > 0x7fffffff) return fail(LSLAM_ERR_BAD_ARG, "in_off is not monotone at %d", k);
+      if (n > max_n) max_n = n;
+    }
+    total = in_off[K];
+    if (total > 0 && !in_xy) return fail(LSLAM_ERR_BAD_ARG, "null input points");
+  }
+  if (K == 0) { out_off[0] = 0; return LSLAM_OK; }
+  if (total > 0 && !out_xy) return fail(LSLAM_ERR_BAD_ARG, "null output buffer");
+  int rc;
+  if ((rc = use_device(device)) != LSLAM_OK) return rc;
+  hipStream_t st;
+  if ((rc = thread_stream(&st)) != LSLAM_OK) return rc;
+
+  // device scratch: two point buffers (ping-pong), two offset arrays, masks, counts, statistics
+  const size_t nb = (size_t)(B > 0 ? B : 1);
+  const size_t b_pts = sizeof(double) * 2 * (size_t)(total > 0 ? total : 1);
+  const size_t b_off = sizeof(int64_t) * ((size_t)K + 1);
+  Arena& ar = thread_arena();
+  const size_t need = Arena::align(sizeof(double) * (size_t)(total > 0 ? total : 1)) + 2 * Arena::align(sizeof(double) * nb) +
+                      2 * Arena::align(b_pts) + 2 * Arena::align(b_off) + 2 * Arena::align((size_t)total + 16) +
+                      Arena::align(sizeof(int32_t) * (size_t)K) + Arena::align(sizeof(double) * (kRadialParts + 8));
+  if ((rc = ar.reserve(device, need)) != LSLAM_OK) return rc;
+  double* d_ranges = static_cast<double*>(ar.carve(sizeof(double) * (size_t)(total > 0 ? total : 1)));
+  double* d_cos = static_cast<double*>(ar.carve(sizeof(double) * nb));
+  double* d_sin = static_cast<double*>(ar.carve(sizeof(double) * nb));
+  double* d_pts[2] = {static_cast<double*>(ar.carve(b_pts)), static_cast<double*>(ar.carve(b_pts))};
+  int64_t* d_off[2] = {static_cast<int64_t*>(ar.carve(b_off)), static_cast<int64_t*>(ar.carve(b_off))};
+  uint8_t* d_keep = static_cast<uint8_t*>(ar.carve((size_t)total + 16));
+  uint8_t* d_core = static_cast<uint8_t*>(ar.carve((size_t)total + 16));
+  int32_t* d_cnt = static_cast<int32_t*>(ar.carve(sizeof(int32_t) * (size_t)K));
+  double* d_partial = static_cast<double*>(ar.carve(sizeof(double) * (kRadialParts + 8)));
+  double* d_stats = d_partial + kRadialParts;
+
+  int cur = 0;            // d_pts[cur] / d_off[cur] hold the current CSR
+  if (polar) {
+    LSLAM_HIP_TRY(hipMemcpyAsync(d_ranges, ranges, sizeof(double) * (size_t)total, hipMemcpyHostToDevice, st));
+    LSLAM_HIP_TRY(hipMemcpyAsync(d_cos, cos_a, sizeof(double) * B, hipMemcpyHostToDevice, st));
+    LSLAM_HIP_TRY(hipMemcpyAsync(d_sin, sin_a, sizeof(double) * B, hipMemcpyHostToDevice, st));
+    LSLAM_HIP_TRY(launch_polar_mask(d_ranges, K, B, d_cos, d_sin, off_x, off_y, range_min, range_max, d_pts[1], d_keep, d_cnt, st));
+    LSLAM_HIP_TRY(launch_compact(d_pts[1], nullptr, B, d_keep, d_cnt, K, d_off[0], d_pts[0], st));
+  } else {
+    if (total > 0) LSLAM_HIP_TRY(hipMemcpyAsync(d_pts[0], in_xy, sizeof(double) * 2 * (size_t)total, hipMemcpyHostToDevice, st));
+    LSLAM_HIP_TRY(hipMemcpyAsync(d_off[0], in_off, b_off, hipMemcpyHostToDevice, st));
+  }
+  if (stages & LSLAM_PRE_DBSCAN) {
+    LSLAM_HIP_TRY(launch_dbscan_mask(d_pts[cur], d_off[cur], K, max_n, eps, min_samples, d_core, d_keep, d_cnt, st));
+    LSLAM_HIP_TRY(launch_compact(d_pts[cur], d_off[cur], 0, d_keep, d_cnt, K, d_off[cur ^ 1], d_pts[cur ^ 1], st));
+    cur ^= 1;
+  }
+  if (stages & LSLAM_PRE_RADIAL) {
+    // the statistics run over the points that are left: their number is on the device
+    int64_t left = 0;
+    LSLAM_HIP_TRY(hipMemcpyAsync(&left, d_off[cur] + K, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    LSLAM_HIP_TRY(hipStreamSynchronize(st));
+    LSLAM_HIP_TRY(launch_radial_mask(d_pts[cur], d_off[cur], K, left, k_std, d_partial, d_stats, d_keep, d_cnt, st));
+    LSLAM_HIP_TRY(launch_compact(d_pts[cur], d_off[cur], 0, d_keep, d_cnt, K, d_off[cur ^ 1], d_pts[cur ^ 1], st));
+    cur ^= 1;
+    if (out_stats) LSLAM_HIP_TRY(hipMemcpyAsync(out_stats, d_stats, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
+  }
+  LSLAM_HIP_TRY(hipMemcpyAsync(out_off, d_off[cur], b_off, hipMemcpyDeviceToHost, st));
+  LSLAM_HIP_TRY(hipStreamSynchronize(st));
+  if (out_off[K] > 0)
+    LSLAM_HIP_TRY(hipMemcpy(out_xy, d_pts[cur], sizeof(double) * 2 * (size_t)out_off[K], hipMemcpyDeviceToHost));
+  return LSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 extern "C++" {
 namespace {
 struct Ogm {

@@ -142,4 +142,16 @@ hipError_t launch_ogm_apply(const OgmGrid& g, int nscans, int parity, int clear_
 hipError_t launch_ogm_binarize(const OgmGrid& g, uint8_t* out, hipStream_t stream);
 hipError_t launch_ogm_init(const OgmGrid& g, hipStream_t stream);
 
+// ---- LiDAR pre-processing (lslam_preprocess.hip) ----------------------------------------------------
+constexpr int kRadialParts = 1024;
+hipError_t launch_polar_mask(const double* ranges, int32_t K, int32_t B, const double* cos_a, const double* sin_a,
+                             double off_x, double off_y, double rmin, double rmax, double* xy_full, uint8_t* keep,
+                             int32_t* counts, hipStream_t st);
+hipError_t launch_dbscan_mask(const double* xy, const int64_t* off, int32_t K, int64_t max_n, double eps, int32_t min_samples,
+                              uint8_t* core, uint8_t* keep, int32_t* counts, hipStream_t st);
+hipError_t launch_radial_mask(const double* xy, const int64_t* off, int32_t K, int64_t total, double k_std, double* partial,
+                              double* stats, uint8_t* keep, int32_t* counts, hipStream_t st);
+hipError_t launch_compact(const double* xy, const int64_t* in_off, int32_t B, const uint8_t* keep, const int32_t* counts,
+                          int32_t K, int64_t* out_off, double* out_xy, hipStream_t st);
+
 }  // namespace lslam

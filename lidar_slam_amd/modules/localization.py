@@ -103,6 +103,85 @@ def save_scan_matching_outputs(poses, relative_poses, dataset_num, out_dir="outp
     return paths
 
 
+# ---------------------------------------------------------------------------------------------
+# LiDAR pre-processing (modules/localization.py:201-307), on the device
+LIDAR_OFFSET = (0.13323, 0.0)             # p_rl[:2], localization.py:297
+_ANGLE_MIN, _ANGLE_MAX = -135 * (np.pi / 180), 135 * (np.pi / 180)
+
+
+def _split(xy, off):
+    return [xy[off[k]:off[k + 1]] for k in range(off.shape[0] - 1)]
+
+
+def _pack64(z_ts):
+    off = np.zeros(len(z_ts) + 1, dtype=np.int64)
+    arrs = [np.asarray(z, dtype=np.float64).reshape(-1, 2) for z in z_ts]
+    off[1:] = np.cumsum([a.shape[0] for a in arrs])
+    flat = np.ascontiguousarray(np.concatenate(arrs, axis=0)) if arrs else np.zeros((0, 2))
+    return flat, off
+
+
+def preprocess_lidar(lidar_ranges=None, lidar_range_min=0.1, lidar_range_max=30.0, z_ts=None, dbscan=None,
+                     k_std=None, device=0, return_stats=False):
+    """The whole chain of main.py:84-87 in one library call, intermediate results staying on the GPU:
+    ``get_lidar_data`` (when ``lidar_ranges`` (K, B) is given, else start from ``z_ts``) →
+    ``DBSCAN_outliers_removal`` (``dbscan=(eps, min_samples)``) → ``statistical_outliers_removal``
+    (``k_std``).  Returns the list of (n_k, 2) float64 scans [, (mean, std, threshold)]."""
+    from .. import _lib
+    from .._lib import check, lib, ptr
+    stages = 0
+    ranges = cos_a = sin_a = in_xy = in_off = None
+    K = B = 0
+    if lidar_ranges is not None:
+        ranges = np.ascontiguousarray(lidar_ranges, dtype=np.float64)
+        K, B = ranges.shape
+        angles = np.linspace(_ANGLE_MIN, _ANGLE_MAX, B)            # localization.py:272-278
+        cos_a, sin_a = np.cos(angles), np.sin(angles)
+        stages |= _lib.PRE_POLAR
+        cap = K * B
+    else:
+        in_xy, in_off = _pack64(z_ts)
+        K = in_off.shape[0] - 1
+        cap = int(in_off[-1])
+    eps, min_samples = (dbscan if dbscan is not None else (0.0, 0))
+    if dbscan is not None:
+        stages |= _lib.PRE_DBSCAN
+    if k_std is not None:
+        stages |= _lib.PRE_RADIAL
+    out_xy = np.empty((max(cap, 1), 2), dtype=np.float64)
+    out_off = np.zeros(K + 1, dtype=np.int64)
+    stats = np.zeros(3, dtype=np.float64)
+    check(lib().lslam_lidar_preprocess(stages, ptr(ranges), K, B, ptr(cos_a), ptr(sin_a), LIDAR_OFFSET[0], LIDAR_OFFSET[1],
+                                       float(lidar_range_min), float(lidar_range_max), ptr(in_xy), ptr(in_off),
+                                       float(eps), int(min_samples), float(k_std if k_std is not None else 0.0),
+                                       ptr(out_xy), ptr(out_off), ptr(stats), int(device)))
+    scans = [a.copy() for a in _split(out_xy, out_off)]
+    return (scans, tuple(stats)) if return_stats else scans
+
+
+def get_lidar_data(lidar_ranges, lidar_range_min, lidar_range_max):
+    """(N, 1081) ranges → list of (n_i, 2) robot-frame points: beams over [−135°, 135°], ranges
+    outside [min, max] dropped, lidar→body offset added (modules/localization.py:252-307)."""
+    return preprocess_lidar(lidar_ranges, lidar_range_min, lidar_range_max)
+
+
+def DBSCAN_outliers_removal(z_ts, eps=0.5, min_samples=10):
+    """Drop the points sklearn's ``DBSCAN(eps, min_samples)`` labels −1
+    (modules/localization.py:201-221): a point stays iff it is a core point or within eps of one."""
+    print(f"DBSCAN: eps={eps}, min_samples={min_samples}")
+    return preprocess_lidar(z_ts=z_ts, dbscan=(eps, min_samples))
+
+
+def statistical_outliers_removal(z_ts, k_std=3):
+    """Drop the points farther than mean + k_std·std of all ranges (modules/localization.py:223-250)."""
+    print(f"Statistical outliers removal: k_std={k_std}")
+    scans, (mean, std, thr) = preprocess_lidar(z_ts=z_ts, k_std=k_std, return_stats=True)
+    print(f"Mean distance: {mean:.3f}")
+    print(f"Std distance: {std:.3f}")
+    print(f"Threshold distance: {thr:.3f}")
+    return scans
+
+
 def poses_from_scan_matching(x_ts, z_ts, return_relative_poses=False):
     """Refine the odometry trajectory by frame-to-frame scan matching
     (modules/localization.py:95-134): same arguments, same returns —

@@ -111,23 +111,26 @@ class ScanSequence:
     x_ts: np.ndarray        # (N,3) odometry poses (truth + drift)
     true_poses: np.ndarray  # (N,3)
     z_ts: list              # N arrays (n_i, 2)
+    ranges: np.ndarray = None   # (N, 1081) raw ranges, dropped beams = 0 (below range_min)
 
 
-def sequence_c3(n_scans: int = 4956, seed: int = 20, drop=(0.0, 0.4)) -> ScanSequence:
+def sequence_c3(n_scans: int = 4956, seed: int = 20, drop=(0.0, 0.4), half: float = 12.0,
+                n_obstacles: int = 14) -> ScanSequence:
     """dataset-20-like: per-step motion inside the measured envelope (|Δθ| ≤ 0.12 rad, |t| ≤ 0.4 m),
     1081 beams over ±135°, 5 mm range noise, a random share of beams dropped per scan
     (stands for --filter_lidar; 650–1081 points per scan), odometry = truth + slow drift."""
     rng = np.random.default_rng(seed)
-    segs, boxes = floor_plan(seed)
+    segs, boxes = floor_plan(seed, half=half, n_obstacles=n_obstacles)
     angles = np.linspace(-FOV, FOV, N_BEAMS)
     poses = np.zeros((n_scans, 3))
+    lim = half - 1.5
     v, w = 0.0, 0.0
     for i in range(1, n_scans):
         v = np.clip(0.97 * v + rng.normal(0, 0.004), 0.0, 0.03)                # m per 25 ms step
         w = np.clip(0.95 * w + rng.normal(0, 0.003), -0.02, 0.02)
         x, y, th = poses[i - 1]
         nx, ny = x + v * np.cos(th), y + v * np.sin(th)
-        blocked = abs(nx) > 10.5 or abs(ny) > 10.5 or any(
+        blocked = abs(nx) > lim or abs(ny) > lim or any(
             b[0] - 0.6 < nx < b[2] + 0.6 and b[1] - 0.6 < ny < b[3] + 0.6 for b in boxes[1:])
         if blocked:                                                           # turn in place
             nx, ny, w = x, y, 0.02
@@ -137,10 +140,11 @@ def sequence_c3(n_scans: int = 4956, seed: int = 20, drop=(0.0, 0.4)) -> ScanSeq
     z_ts = []
     for i in range(n_scans):
         keep = rng.random(N_BEAMS) >= rng.uniform(*drop)
-        z_ts.append(scan_points(np.where(keep, ranges[i], 0.0), angles))
+        ranges[i] = np.where(keep, ranges[i], 0.0)
+        z_ts.append(scan_points(ranges[i], angles))
     drift = np.cumsum(rng.normal(0, [0.0008, 0.0008, 0.0005], (n_scans, 3)), axis=0)
     drift[0] = 0
-    return ScanSequence(x_ts=poses + drift, true_poses=poses, z_ts=z_ts)
+    return ScanSequence(x_ts=poses + drift, true_poses=poses, z_ts=z_ts, ranges=ranges)
 
 
 # ---------------------------------------------------------------------------------------------- C4

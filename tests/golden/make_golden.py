@@ -300,3 +300,23 @@ save("se2_outputs20.npz", poses_odom=out["poses_odom"][:K + 1],
      poses_scan_matching=out["poses_scan_matching"][:K + 1],
      relative_poses_scan_matching=out["relative_poses_scan_matching"][:K])
 print("done")
+
+# ------------------------------------------------- pre-processing
+# get_lidar_data -> DBSCAN_outliers_removal(eps=0.1, min_samples=10) -> statistical_outliers_removal(k_std=2)
+# exactly as main.py:84-87 chains them
+rng = np.random.default_rng(84)
+R = np.tile(ranges, (8, 1))
+R[1] *= 0.6
+R[2] = np.roll(ranges, 37) + rng.normal(0, 0.01, ranges.shape)
+R[3, ::7] = 0.0                      # invalid beams
+R[4, 100:140] = 45.0                 # beyond range_max
+R[5] = ranges * rng.uniform(0.9, 1.1, ranges.shape)
+R[6] = np.clip(ranges + rng.normal(0, 0.3, ranges.shape), 0.0, None)      # noisy: many DBSCAN outliers
+R[7, 500:520] += 6.0                 # a far blob: radial outliers
+z0 = ref_loc.get_lidar_data(R, 0.1, 30)
+z1 = ref_loc.DBSCAN_outliers_removal(z0, eps=0.1, min_samples=10)
+z2 = ref_loc.statistical_outliers_removal(z1, k_std=2)
+a0, o0 = ragged(z0); a1, o1 = ragged(z1); a2, o2 = ragged(z2)
+save("lidar_pre.npz", ranges=R, xy0=a0, off0=o0, xy1=a1, off1=o1, xy2=a2, off2=o2,
+     range_min=0.1, range_max=30.0, eps=0.1, min_samples=10, k_std=2)
+print("  pre-processing sizes:", np.diff(o0).tolist(), np.diff(o1).tolist(), np.diff(o2).tolist())

@@ -1,0 +1,48 @@
+"""LiDAR pre-processing on the GPU vs the reference chain (golden) and the oracle."""
+import numpy as np
+import pytest
+
+from conftest import golden, split
+
+pytestmark = pytest.mark.gpu
+
+
+def test_each_stage_matches_reference_exactly():
+    from lidar_slam_amd.modules import localization as L
+    g = golden("lidar_pre.npz")
+    z0 = L.get_lidar_data(g["ranges"], float(g["range_min"]), float(g["range_max"]))
+    for a, b in zip(z0, split(g["xy0"], g["off0"])):
+        np.testing.assert_array_equal(a, b)                      # bit-exact points
+    z1 = L.DBSCAN_outliers_removal(split(g["xy0"], g["off0"]), eps=float(g["eps"]), min_samples=int(g["min_samples"]))
+    for a, b in zip(z1, split(g["xy1"], g["off1"])):
+        np.testing.assert_array_equal(a, b)                      # same survivors, same order
+    z2 = L.statistical_outliers_removal(split(g["xy1"], g["off1"]), k_std=float(g["k_std"]))
+    for a, b in zip(z2, split(g["xy2"], g["off2"])):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_fused_chain_matches_reference():
+    from lidar_slam_amd.modules.localization import preprocess_lidar
+    g = golden("lidar_pre.npz")
+    scans, (mean, std, thr) = preprocess_lidar(g["ranges"], float(g["range_min"]), float(g["range_max"]),
+                                               dbscan=(float(g["eps"]), int(g["min_samples"])), k_std=float(g["k_std"]),
+                                               return_stats=True)
+    for a, b in zip(scans, split(g["xy2"], g["off2"])):
+        np.testing.assert_array_equal(a, b)
+    d = np.sqrt(np.sum(g["xy1"] ** 2, axis=1))
+    assert abs(mean - d.mean()) < 1e-12 and abs(std - d.std()) < 1e-12 and abs(thr - (d.mean() + 2 * d.std())) < 1e-12
+
+
+def test_random_scans_against_oracle_including_empty_and_large():
+    from lidar_slam_amd.modules.localization import preprocess_lidar
+    from oracle import preprocess_oracle as P
+    rng = np.random.default_rng(9)
+    z = [rng.normal(size=(n, 2)) * s for n, s in ((0, 1), (1, 1), (9, 0.05), (300, 0.3), (5000, 2.0), (64, 0.02), (257, 0.5))]
+    got = preprocess_lidar(z_ts=z, dbscan=(0.1, 10))
+    exp = P.dbscan_outliers_removal(z, 0.1, 10)
+    for a, b in zip(got, exp):
+        np.testing.assert_array_equal(a, b)
+    got = preprocess_lidar(z_ts=z, k_std=1.0)
+    exp = P.statistical_outliers_removal(z, 1.0)
+    for a, b in zip(got, exp):
+        np.testing.assert_array_equal(a, b)
