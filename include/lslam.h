@@ -142,6 +142,12 @@ int lslam_kabsch(const double *p, int64_t p_stride, const double *q, int64_t q_s
 int lslam_sq_error(const double *p, const double *q, int64_t n, int32_t cols,
                    int32_t normalize, double *out_err, int device);
 
+/* ---- pose chain: modules/localization.py:111-130 ------------------------------------ */
+/* Sequential float64 product of S relative 3x3 transforms starting at the identity, reported
+ * as (x, y, atan2(T10, T00)) after every step: out_poses is (S+1) x 3 with row 0 = (0,0,0).
+ * Pure host arithmetic (the chain is inherently sequential and O(S)); no GPU involved. */
+int lslam_chain_se2(const double *rel_T3, int64_t S, double *out_poses);
+
 /* ---- LiDAR pre-processing: modules/localization.py:201-307 (main.py:84-87) ---------- */
 /*
  * The chain in front of the ICP path, kept on the device between its stages:

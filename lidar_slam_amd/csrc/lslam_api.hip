@@ -93,6 +93,7 @@ static IcpBatchTuning tuning_from_env() {
   if (const char* e = getenv("LSLAM_ICP_POINTS_PER_LANE")) t.points_per_lane = atoi(e);
   if (const char* e = getenv("LSLAM_ICP_THREADS")) t.threads = atoi(e);
   if (const char* e = getenv("LSLAM_ICP_TILE_POINTS")) t.tile_points = atoi(e);
+  if (const char* e = getenv("LSLAM_ICP_VARIANT")) t.variant = atoi(e);
   return t;
 }
 
@@ -418,6 +419,25 @@ int lslam_sq_error(const double* p, const double* q, int64_t n, int32_t cols, in
   if (!p || !q || !out_err) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
   if (n < 0 || cols < 1 || cols > 3) return fail(LSLAM_ERR_BAD_ARG, "need n >= 0 and 1 <= cols <= 3");
   return pair_op(p, cols, q, cols, n, cols, normalize, nullptr, out_err, device);
+}
+
+// ---------------------------------------------------------------------------------------------------
+int lslam_chain_se2(const double* rel, int64_t S, double* out) {
+  clear_error();
+  if (S < 0 || !out || (S > 0 && !rel)) return fail(LSLAM_ERR_BAD_ARG, "bad arguments");
+  double T[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  out[0] = out[1] = out[2] = 0.0;
+  for (int64_t k = 0; k < S; ++k) {
+    const double* R = rel + 9 * k;
+    double N[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) N[3 * i + j] = T[3 * i] * R[j] + T[3 * i + 1] * R[3 + j] + T[3 * i + 2] * R[6 + j];
+    for (int i = 0; i < 9; ++i) T[i] = N[i];
+    out[3 * (k + 1)] = T[2];
+    out[3 * (k + 1) + 1] = T[5];
+    out[3 * (k + 1) + 2] = atan2(T[3], T[0]);
+  }
+  return LSLAM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------

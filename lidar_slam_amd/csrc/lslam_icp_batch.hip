@@ -97,16 +97,14 @@ __device__ __forceinline__ void sweep_tile(const typename TilePoint<DIM>::type* 
   }
 }
 
-template <int DIM, int P>
-__global__ void __launch_bounds__(kIcpBatchMaxThreads)
-icp_batch_kernel(IcpBatchArgs args) {
-  constexpr int CHUNK = IcpChunk<DIM>::value;
+template <int DIM, int P, int CHUNK>
+__device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
   using TP = typename TilePoint<DIM>::type;
   constexpr int kAcc = AccLayout<DIM>::kTotal;
   extern __shared__ __align__(16) unsigned char smem[];
   TP* tile = reinterpret_cast<TP*>(smem);
   double* sh_red = reinterpret_cast<double*>(smem + args.tile_bytes);        // [waves][kAcc]
-  double* sh_T = sh_red + (size_t)kIcpBatchMaxWaves * kAcc;                   // 16
+  double* sh_T = sh_red + (size_t)kIcpBatchMaxWaves * kAcc;                   // current transform, 16
   int* sh_flag = reinterpret_cast<int*>(sh_T + 16);                           // [0] stop
 
   const int pair = blockIdx.x;
@@ -140,10 +138,13 @@ icp_batch_kernel(IcpBatchArgs args) {
   // pair to the float64 moments.  Only the float32 copies of the points live across the sweep;
   // the float64 transform is re-evaluated afterwards from the (L2-resident) source.
   auto run_pass = [&](int base, const double (&T)[3][4], PairAcc<DIM>& acc) {
+    // waves whose first lane is already past the last source point skip the sweep and the fix-up
+    // (scans of a batch differ in size; the launch is sized for the largest)
+    const bool wave_live = base + (tid & ~(kWave - 1)) * P < n;
     float a[P][DIM];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const int i = base + p * blockDim.x + tid;
+      const int i = base + tid * P + p;                  // lane-consecutive: tail waves own no point at all
       double x = 0.0, y = 0.0, z = 0.0;
       if (i < n) {
         if constexpr (DIM == 2) {
@@ -167,7 +168,7 @@ icp_batch_kernel(IcpBatchArgs args) {
 #pragma unroll
     for (int p = 0; p < P; ++p) { best[p] = INFINITY; bchunk[p] = 0; }
     if (resident) {
-      sweep_tile<DIM, P, CHUNK>(tile, (m + CHUNK - 1) / CHUNK, 0, a, best, bchunk);
+      if (wave_live) sweep_tile<DIM, P, CHUNK>(tile, (m + CHUNK - 1) / CHUNK, 0, a, best, bchunk);
     } else {
       for (int t = 0; t < ntiles; ++t) {
         const int first = t * tile_cap;
@@ -175,11 +176,12 @@ icp_batch_kernel(IcpBatchArgs args) {
         __syncthreads();                                     // previous tile fully consumed
         stage_tile<DIM>(gtgt + (int64_t)DIM * first, cnt, ((cnt + CHUNK - 1) / CHUNK) * CHUNK, tile);
         __syncthreads();
-        sweep_tile<DIM, P, CHUNK>(tile, (cnt + CHUNK - 1) / CHUNK, first / CHUNK, a, best, bchunk);
+        if (wave_live) sweep_tile<DIM, P, CHUNK>(tile, (cnt + CHUNK - 1) / CHUNK, first / CHUNK, a, best, bchunk);
       }
     }
 
     // ---- fix-up: exact index inside the winning chunk; moments in float64 --------------------
+    if (!wave_live) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int j0 = bchunk[p] * CHUNK;
@@ -187,7 +189,10 @@ icp_batch_kernel(IcpBatchArgs args) {
       int bi = j0;
       float q[DIM] = {};
 #pragma unroll
-      for (int k = 0; k < CHUNK; ++k) {
+      for (int kk = 0; kk < CHUNK; ++kk) {
+        // every lane starts at a different point of its chunk: all chunks begin on the same LDS
+        // banks, an unrotated gather would be a 32-way bank conflict
+        const int k = (kk + lane) & (CHUNK - 1);
         const int j = j0 + k;
         float bx, by, bz = 0.f;
         if (resident) {
@@ -203,12 +208,12 @@ icp_batch_kernel(IcpBatchArgs args) {
         float d;
         if constexpr (DIM == 2) d = dist2(a[p][0], a[p][1], bx, by);
         else d = dist2(a[p][0], a[p][1], a[p][2], bx, by, bz);
-        if (d < bd || k == 0) {
+        if (kk == 0 || d < bd || (d == bd && j < bi)) {      // lowest index on ties, whatever the visiting order
           bd = d; bi = j; q[0] = bx; q[1] = by;
           if constexpr (DIM == 3) q[2] = bz;
         }
       }
-      const int i = base + p * blockDim.x + tid;
+      const int i = base + tid * P + p;
       if (i < n) {
         double x, y, z = 0.0;
         if constexpr (DIM == 2) {
@@ -248,20 +253,43 @@ icp_batch_kernel(IcpBatchArgs args) {
       for (int pass = 0; pass < passes; ++pass) run_pass(pass * src_per_pass, T, acc);
     }
 
-    // ---- block reduction → lane 0 solves -------------------------------------------------------
+    // ---- block reduction: wave rows → LDS → wave 0 combines and solves -----------------------
     acc.wave_reduce(box);
     if (lane == 0) acc.store(sh_red + (size_t)wave * kAcc);
     __syncthreads();
-    if (tid == 0) {
+    if (wave == 0) {
+      // lane k sums column k over the waves in wave order (fixed order → bitwise reproducible) ...
+      constexpr int kS = AccLayout<DIM>::kSums;
+      double col = 0.0;
+      if (lane < kAcc) {
+        col = sh_red[lane];
+        for (int w = 1; w < nwaves; ++w) {
+          const double v = sh_red[(size_t)w * kAcc + lane];
+          col = (lane < kS) ? col + v : ((lane < kS + DIM) ? fmin(col, v) : fmax(col, v));
+        }
+      }
+      // ... the totals reach every lane through scalar registers, and the (uniform) solve runs once
+      double tot[kAcc];
+#pragma unroll
+      for (int k = 0; k < kAcc; ++k) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(col), k);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(col), k);
+        tot[k] = __hiloint2double(hi, lo);
+      }
       Moments mo;
-      combine_partials<DIM>(sh_red, nwaves, kAcc, box, mo);
+      combine_partials<DIM>(tot, 1, kAcc, box, mo);
       double Tstep[16], Tprev[16], Tnew[16];
       step_from_moments(mo, DIM == 2, Tstep);
+#pragma unroll
       for (int i = 0; i < 16; ++i) Tprev[i] = sh_T[i];
       matmul4(Tstep, Tprev, Tnew);                           // icp.py:119
-      for (int i = 0; i < 16; ++i) sh_T[i] = Tnew[i];
       err_out = error_from_moments(mo, box);                 // icp.py:120 (pre-update residual)
-      sh_flag[0] = stop_after_iteration(st, err_out, args.epsilon, args.stopping_thresh, args.max_iters) ? 1 : 0;
+      const bool stop = stop_after_iteration(st, err_out, args.epsilon, args.stopping_thresh, args.max_iters);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sh_T[i] = Tnew[i];
+        sh_flag[0] = stop ? 1 : 0;
+      }
     }
     __syncthreads();
     if (sh_flag[0]) break;
@@ -274,35 +302,60 @@ icp_batch_kernel(IcpBatchArgs args) {
   }
 }
 
+// Two builds of the same body:
+//   icp_batch_kernel        up to 1024 lanes per problem, 128 VGPRs: big clouds (C4), chunk = IcpChunk;
+//   icp_batch_small_kernel  capped at 64 VGPRs (8 waves per SIMD) with a smaller
+//                           chunk: LiDAR-sized problems (≤ ~1000 points) leave most of an iteration's
+//                           wall time in barriers and the one-lane solve, so several workgroups must
+//                           be resident per CU to keep the VALUs fed.
+template <int DIM, int P>
+__global__ void __launch_bounds__(kIcpBatchMaxThreads)
+icp_batch_kernel(IcpBatchArgs args) {
+  icp_batch_body<DIM, P, IcpChunk<DIM>::value>(args);
+}
+
+template <int DIM, int P>
+__global__ void __launch_bounds__(kIcpSmallMaxThreads, 8)
+icp_batch_small_kernel(IcpBatchArgs args) {
+  icp_batch_body<DIM, P, IcpChunkSmall<DIM>::value>(args);
+}
+
 // ---- launch ------------------------------------------------------------------------------------
 template <int DIM, int P>
-static hipError_t launch_one(const IcpBatchArgs& a, int S, int threads, size_t smem, hipStream_t stream) {
-  auto k = icp_batch_kernel<DIM, P>;
+static hipError_t launch_one(const IcpBatchArgs& a, int S, int threads, size_t smem, bool small, hipStream_t stream) {
+  const void* fn = small ? reinterpret_cast<const void*>(icp_batch_small_kernel<DIM, P>)
+                         : reinterpret_cast<const void*>(icp_batch_kernel<DIM, P>);
   if (smem > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k, dim3(S), dim3(threads), smem, stream, a);
+  if (small) hipLaunchKernelGGL((icp_batch_small_kernel<DIM, P>), dim3(S), dim3(threads), smem, stream, a);
+  else hipLaunchKernelGGL((icp_batch_kernel<DIM, P>), dim3(S), dim3(threads), smem, stream, a);
   return hipGetLastError();
 }
 
 hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, int64_t max_tgt_n,
                             const IcpBatchTuning& tune, hipStream_t stream) {
-  const int CHUNK = (dim == 2) ? IcpChunk<2>::value : IcpChunk<3>::value;
   // points per lane
   int P = tune.points_per_lane;
-  if (P == 0) P = (max_src_n <= 2048) ? 2 : 4;
+  if (P == 0) P = (max_src_n <= 512) ? 1 : ((max_src_n <= 2048) ? 2 : 4);
   if (P != 1 && P != 2 && P != 4) return hipErrorInvalidValue;
   int64_t lanes = (max_src_n + P - 1) / P;
   int threads = (int)(((lanes + kWave - 1) / kWave) * kWave);
   if (threads < kWave) threads = kWave;
   if (threads > kIcpBatchMaxThreads) threads = kIcpBatchMaxThreads;
   if (tune.threads > 0) threads = tune.threads;
+  bool small = threads <= kIcpSmallAutoThreads && max_tgt_n <= kIcpSmallMaxTargets;
+  if (tune.variant == 1) small = false;
+  if (tune.variant == 2 && threads <= kIcpSmallMaxThreads) small = true;
+  const int CHUNK = small ? ((dim == 2) ? IcpChunkSmall<2>::value : IcpChunkSmall<3>::value)
+                          : ((dim == 2) ? IcpChunk<2>::value : IcpChunk<3>::value);
 
   // LDS tile
   const int pt_bytes = (dim == 2) ? 8 : 16;
   int cap = (dim == 2) ? kIcpTileMaxPlanar : kIcpTileMax3D;
-  if (tune.tile_points > 0) cap = ((tune.tile_points + CHUNK - 1) / CHUNK) * CHUNK;
+  if (tune.tile_points > 0) cap = tune.tile_points;
+  cap = ((cap + 15) / 16) * 16;                              // a multiple of every chunk size
   int64_t need = ((max_tgt_n + CHUNK - 1) / CHUNK) * CHUNK;
   if (need < CHUNK) need = CHUNK;
   const int tile_points = (int)(need < cap ? need : cap);
@@ -312,13 +365,13 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
   const size_t smem = a.tile_bytes + sizeof(double) * ((size_t)kIcpBatchMaxWaves * kAcc + 16) + 16;
 
   if (dim == 2) {
-    if (P == 1) return launch_one<2, 1>(a, S, threads, smem, stream);
-    if (P == 2) return launch_one<2, 2>(a, S, threads, smem, stream);
-    return launch_one<2, 4>(a, S, threads, smem, stream);
+    if (P == 1) return launch_one<2, 1>(a, S, threads, smem, small, stream);
+    if (P == 2) return launch_one<2, 2>(a, S, threads, smem, small, stream);
+    return launch_one<2, 4>(a, S, threads, smem, small, stream);
   }
-  if (P == 1) return launch_one<3, 1>(a, S, threads, smem, stream);
-  if (P == 2) return launch_one<3, 2>(a, S, threads, smem, stream);
-  return launch_one<3, 4>(a, S, threads, smem, stream);
+  if (P == 1) return launch_one<3, 1>(a, S, threads, smem, small, stream);
+  if (P == 2) return launch_one<3, 2>(a, S, threads, smem, small, stream);
+  return launch_one<3, 4>(a, S, threads, smem, small, stream);
 }
 
 }  // namespace lslam

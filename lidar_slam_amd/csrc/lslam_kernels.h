@@ -17,6 +17,13 @@ constexpr uint32_t kFlagNormalize = 1u;   // == LSLAM_ICP_NORMALIZE_ERROR
 template <int DIM> struct IcpChunk;
 template <> struct IcpChunk<2> { static constexpr int value = 16; };
 template <> struct IcpChunk<3> { static constexpr int value = 8; };
+// the 64-VGPR build for LiDAR-sized problems keeps fewer target points in registers
+template <int DIM> struct IcpChunkSmall;
+template <> struct IcpChunkSmall<2> { static constexpr int value = 8; };
+template <> struct IcpChunkSmall<3> { static constexpr int value = 4; };
+constexpr int kIcpSmallMaxThreads = 1024;   // what the 64-VGPR build is compiled for
+constexpr int kIcpSmallAutoThreads = 640;   // automatic choice: problems of up to ~1300 source points
+constexpr int kIcpSmallMaxTargets = 4096;
 
 struct IcpBatchArgs {
   const float* src;          // device, DIM floats per point
@@ -40,6 +47,7 @@ struct IcpBatchTuning {
   int points_per_lane = 0;   // 0 = heuristic; 1, 2 or 4
   int threads = 0;           // 0 = from max_src_n
   int tile_points = 0;       // 0 = default cap
+  int variant = 0;           // 0 = automatic, 1 = force the 128-VGPR build, 2 = force the 64-VGPR build
 };
 
 hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, int64_t max_tgt_n,

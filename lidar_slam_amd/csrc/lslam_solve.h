@@ -43,13 +43,13 @@ LSLAM_HD void polar_planar(const double S[9], double R[9]) {
   R[8] = 1.0;
   if (s00 * s11 - s01 * s10 > 0.0) {
     const double a = s00 + s11, b = s01 - s10;
-    const double h = hypot(a, b);
+    const double h = sqrt(a * a + b * b);      // |S| entries are Σ p·q of metre-scale data: no overflow concern
     const double c = a / h, s = b / h;
     R[0] = c; R[1] = -s; R[3] = s; R[4] = c;
     return;
   }
   const double a = s00 - s11, b = s01 + s10;
-  const double h = hypot(a, b);
+  const double h = sqrt(a * a + b * b);
   if (h == 0.0) { R[0] = 1.0; R[4] = 1.0; return; }
   const double c = a / h, s = b / h;
   R[0] = c; R[1] = s; R[3] = s; R[4] = -c; R[8] = -1.0;

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from ..batch import icp_batch, pack_clouds
+from ..batch import PackedScans, icp_batch, pack_clouds
 from .utils import TSE2_from_TSE3, T_from_pose, pose_from_T  # noqa: F401  (re-exported like the reference)
 
 
@@ -34,12 +34,12 @@ def relative_pose_guesses(x_ts: np.ndarray) -> np.ndarray:
 
 def chain_poses(relative_T3: np.ndarray) -> np.ndarray:
     """Sequential float64 product of (S,3,3) relative transforms from the identity -> (S+1,3) poses
-    (localization.py:111-130)."""
-    T = np.eye(3)
-    poses = np.zeros((relative_T3.shape[0] + 1, 3))
-    for i, Trel in enumerate(relative_T3):
-        T = T @ Trel
-        poses[i + 1] = (T[0, 2], T[1, 2], np.arctan2(T[1, 0], T[0, 0]))
+    (localization.py:111-130).  Runs in the library's host code (``lslam_chain_se2``): the chain is
+    sequential by nature, 4955 tiny matmuls cost more in the Python interpreter than the whole GPU stage."""
+    from .._lib import check, lib, ptr
+    rel = np.ascontiguousarray(relative_T3, dtype=np.float64).reshape(-1, 3, 3)
+    poses = np.empty((rel.shape[0] + 1, 3), dtype=np.float64)
+    check(lib().lslam_chain_se2(ptr(rel), rel.shape[0], ptr(poses)))
     return poses
 
 
@@ -49,7 +49,7 @@ def scan_matching_relative_poses(x_ts, z_ts, device=0, return_info=False):
     S = x_ts.shape[0] - 1
     if len(z_ts) != S + 1:
         raise ValueError("need one scan per pose")
-    pts, off = pack_clouds([np.asarray(z) for z in z_ts])
+    pts, off = pack_clouds(z_ts if isinstance(z_ts, PackedScans) else [np.asarray(z) for z in z_ts])
     if pts.shape[1] != 2:
         raise ValueError("scans must be (n_i, 2) robot-frame points")
     # source = scan i, target = scan i-1 (localization.py:120-121)
@@ -155,7 +155,7 @@ def preprocess_lidar(lidar_ranges=None, lidar_range_min=0.1, lidar_range_max=30.
                                        float(lidar_range_min), float(lidar_range_max), ptr(in_xy), ptr(in_off),
                                        float(eps), int(min_samples), float(k_std if k_std is not None else 0.0),
                                        ptr(out_xy), ptr(out_off), ptr(stats), int(device)))
-    scans = [a.copy() for a in _split(out_xy, out_off)]
+    scans = PackedScans(out_xy[: int(out_off[-1])], out_off)     # list of views of one packed array
     return (scans, tuple(stats)) if return_stats else scans
 
 

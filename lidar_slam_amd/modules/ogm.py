@@ -83,10 +83,14 @@ class OccupancyGridMap:
         (modules/ogm.py:45-64).  One library call for the whole trajectory."""
         states = np.ascontiguousarray(np.asarray(states, dtype=np.float64)[:, :3])
         K = states.shape[0]
-        off = np.zeros(K + 1, dtype=np.int64)
-        scans = [np.asarray(meas[i], dtype=np.float64).reshape(-1, 2) for i in range(K)]
-        off[1:] = np.cumsum([s.shape[0] for s in scans])
-        flat = np.ascontiguousarray(np.concatenate(scans, axis=0)) if K else np.zeros((0, 2))
+        from ..batch import PackedScans
+        if isinstance(meas, PackedScans) and len(meas) == K and meas.flat.dtype == np.float64:
+            flat, off = np.ascontiguousarray(meas.flat), meas.off          # already packed: no copies
+        else:
+            off = np.zeros(K + 1, dtype=np.int64)
+            scans = [np.asarray(meas[i], dtype=np.float64).reshape(-1, 2) for i in range(K)]
+            off[1:] = np.cumsum([s.shape[0] for s in scans])
+            flat = np.ascontiguousarray(np.concatenate(scans, axis=0)) if K else np.zeros((0, 2))
         check(lib().lslam_ogm_update(self._handle, ptr(states), ptr(flat), ptr(off), K))
         self._host_stale = True
         out = np.empty(self._shape, dtype=np.uint8)

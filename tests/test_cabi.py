@@ -85,3 +85,11 @@ def test_stop_rules_on_host():
     assert run([5, 4, 3.99995, 1], 0.01, 1e-4, 2000) == 3        # Δ rule needs a previous error
     assert run([0.001, 5], 0.01, 1e-4, 2000) == 1                # epsilon fires first
     assert run([5] * 60, 0.0, 0.0, 49) == 50                     # "50 forced iterations" (I2)
+
+
+def test_pose_chain_reproduces_reference_outputs_without_gpu():
+    """lslam_chain_se2 is host arithmetic: the reference's committed relative poses chain to its poses"""
+    from lidar_slam_amd.modules.localization import chain_poses
+    g = golden("se2_outputs20.npz")
+    np.testing.assert_allclose(chain_poses(g["relative_poses_scan_matching"]), g["poses_scan_matching"], atol=1e-12)
+    assert chain_poses(np.zeros((0, 3, 3))).tolist() == [[0.0, 0.0, 0.0]]
