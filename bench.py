@@ -127,8 +127,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("LSLAM_BENCH_FORCE_DIST") == "1"      # the latter: 1-rank rehearsal of the N > 1 path
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from lidar_slam_amd import batch as B
@@ -137,7 +139,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     result = {}
@@ -147,13 +149,13 @@ def main():
         out_T = torch.empty((S, 4, 4), device=device, dtype=torch.float64)
         out_err = torch.empty((S,), device=device, dtype=torch.float64)
         out_it = torch.empty((S,), device=device, dtype=torch.int32)
-        gathered = torch.empty((world * S, 4, 4), device=device, dtype=torch.float64) if world > 1 else None
+        gathered = torch.empty((world * S, 4, 4), device=device, dtype=torch.float64) if use_dist else None
 
         def step():
             B.icp_batch_dev(src.data_ptr(), off.data_ptr(), tgt.data_ptr(), off.data_ptr(), 2, init.data_ptr(), S, P, P,
                             out_T.data_ptr(), out_err.data_ptr(), out_it.data_ptr(), None, epsilon=0.0,
                             max_iters=I - 1, stopping_thresh=0.0, stream=stream)
-            if world > 1:
+            if use_dist:
                 dist.all_gather_into_tensor(gathered, out_T)       # the one collective: relative poses
 
         for _ in range(a.warmup):
@@ -167,11 +169,11 @@ def main():
                             out_T.data_ptr(), out_err.data_ptr(), out_it.data_ptr(), None, epsilon=0.0,
                             max_iters=I - 1, stopping_thresh=0.0, stream=stream)
             ev[k][1].record()
-            if world > 1:
+            if use_dist:
                 dist.all_gather_into_tensor(gathered, out_T)
         torch.cuda.synchronize(); barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tmax = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
@@ -216,7 +218,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -142,6 +142,13 @@ int lslam_kabsch(const double *p, int64_t p_stride, const double *q, int64_t q_s
 int lslam_sq_error(const double *p, const double *q, int64_t n, int32_t cols,
                    int32_t normalize, double *out_err, int device);
 
+/* ---- voxel_downsample: modules/icp.py:4-27 --------------------------------------------- */
+/* Mean of the points in every occupied voxel of size `voxel_size`, voxels in lexicographic order of
+ * their integer index floor((p - min) / voxel_size).  points: HOST float64 n x dim (dim = 2 or 3);
+ * out: capacity n x dim; *out_count receives the number of voxels.  At most 2^21 voxels per axis. */
+int lslam_voxel_downsample(const double *points, int64_t n, int32_t dim, double voxel_size,
+                           double *out, int64_t *out_count, int device);
+
 /* ---- pose chain: modules/localization.py:111-130 ------------------------------------ */
 /* Sequential float64 product of S relative 3x3 transforms starting at the identity, reported
  * as (x, y, atan2(T10, T00)) after every step: out_poses is (S+1) x 3 with row 0 = (0,0,0).

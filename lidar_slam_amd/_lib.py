@@ -50,6 +50,7 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "lslam_kabsch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int]),
     "lslam_sq_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int]),
+    "lslam_voxel_downsample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_int]),
     "lslam_chain_se2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "lslam_lidar_preprocess": (C.c_int, [C.c_uint32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
                                          C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_double,

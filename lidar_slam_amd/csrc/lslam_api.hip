@@ -422,6 +422,50 @@ int lslam_sq_error(const double* p, const double* q, int64_t n, int32_t cols, in
 }
 
 // ---------------------------------------------------------------------------------------------------
+int lslam_voxel_downsample(const double* points, int64_t n, int32_t dim, double voxel_size, double* out,
+                           int64_t* out_count, int device) {
+  clear_error();
+  if (!out_count) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  *out_count = 0;
+  if (n < 0 || (dim != 2 && dim != 3) || !(voxel_size > 0.0)) return fail(LSLAM_ERR_BAD_ARG, "need n >= 0, dim in {2,3}, voxel_size > 0");
+  if (n == 0) return LSLAM_OK;
+  if (!points || !out) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (n > 0xfffffff0ll) return fail(LSLAM_ERR_BAD_ARG, "more than 2^32 points are not supported");
+  int rc;
+  if ((rc = use_device(device)) != LSLAM_OK) return rc;
+  hipStream_t st;
+  if ((rc = thread_stream(&st)) != LSLAM_OK) return rc;
+  const size_t b_pts = sizeof(double) * (size_t)n * dim;
+  VoxelWs ws{};
+  ws.temp_bytes = voxel_temp_bytes(n);
+  Arena& ar = thread_arena();
+  const size_t need = 2 * Arena::align(b_pts) + Arena::align(sizeof(double) * 3 * 1024) + 2 * Arena::align(64) +
+                      2 * Arena::align(sizeof(unsigned long long) * (size_t)n) + 2 * Arena::align(sizeof(uint32_t) * (size_t)n) +
+                      Arena::align(sizeof(int64_t) * ((size_t)n + 1)) + Arena::align(ws.temp_bytes);
+  if ((rc = ar.reserve(device, need)) != LSLAM_OK) return rc;
+  double* d_pts = static_cast<double*>(ar.carve(b_pts));
+  double* d_out = static_cast<double*>(ar.carve(b_pts));
+  ws.partial = static_cast<double*>(ar.carve(sizeof(double) * 3 * 1024));
+  ws.lo = static_cast<double*>(ar.carve(64));
+  ws.bad = static_cast<int*>(ar.carve(64));
+  ws.keys_in = static_cast<unsigned long long*>(ar.carve(sizeof(unsigned long long) * (size_t)n));
+  ws.keys_out = static_cast<unsigned long long*>(ar.carve(sizeof(unsigned long long) * (size_t)n));
+  ws.ids_in = static_cast<uint32_t*>(ar.carve(sizeof(uint32_t) * (size_t)n));
+  ws.ids_out = static_cast<uint32_t*>(ar.carve(sizeof(uint32_t) * (size_t)n));
+  ws.starts = static_cast<int64_t*>(ar.carve(sizeof(int64_t) * ((size_t)n + 1)));
+  ws.temp = ar.carve(ws.temp_bytes);
+  LSLAM_HIP_TRY(hipMemcpyAsync(d_pts, points, b_pts, hipMemcpyHostToDevice, st));
+  int64_t nvox = 0;
+  int bad = 0;
+  LSLAM_HIP_TRY(run_voxel_downsample(d_pts, n, dim, voxel_size, ws, d_out, &nvox, &bad, st));
+  if (bad) return fail(LSLAM_ERR_BAD_ARG, "voxel grid exceeds 2^21 cells along an axis (or non-finite points)");
+  LSLAM_HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)nvox * dim, hipMemcpyDeviceToHost, st));
+  LSLAM_HIP_TRY(hipStreamSynchronize(st));
+  *out_count = nvox;
+  return LSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 int lslam_chain_se2(const double* rel, int64_t S, double* out) {
   clear_error();
   if (S < 0 || !out || (S > 0 && !rel)) return fail(LSLAM_ERR_BAD_ARG, "bad arguments");

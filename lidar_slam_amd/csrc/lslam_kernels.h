@@ -162,4 +162,20 @@ hipError_t launch_radial_mask(const double* xy, const int64_t* off, int32_t K, i
 hipError_t launch_compact(const double* xy, const int64_t* in_off, int32_t B, const uint8_t* keep, const int32_t* counts,
                           int32_t K, int64_t* out_off, double* out_xy, hipStream_t st);
 
+// ---- voxel_downsample (lslam_voxel.hip) -----------------------------------------------------------------
+struct VoxelWs {
+  double* partial;              // 1024 x 3
+  double* lo;                   // 3
+  int* bad;                     // 1
+  unsigned long long* keys_in;  // n
+  unsigned long long* keys_out; // n
+  uint32_t* ids_in;             // n
+  uint32_t* ids_out;            // n
+  int64_t* starts;              // n + 1
+  void* temp; size_t temp_bytes;
+};
+size_t voxel_temp_bytes(int64_t n);
+hipError_t run_voxel_downsample(const double* pts, int64_t n, int dim, double voxel, VoxelWs ws, double* out,
+                                int64_t* h_nvox, int* h_bad, hipStream_t st);
+
 }  // namespace lslam

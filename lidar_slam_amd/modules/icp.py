@@ -57,18 +57,16 @@ def _keeps_planar(T):
 
 
 def voxel_downsample(point_cloud, voxel_size):
-    """Mean of the points inside every occupied voxel, voxels in lexicographic index order
-    (modules/icp.py:4-27).
-
-    Pre-processing step outside the accelerated path ("next"): it runs on the
-    host, vectorised — one ``np.unique`` and one scatter-add instead of the reference's Python loop
-    over voxels."""
-    pc = np.asarray(point_cloud)
-    vox = np.floor((pc - np.min(pc, axis=0)) / voxel_size).astype(int)
-    _, inverse, counts = np.unique(vox, axis=0, return_inverse=True, return_counts=True)
-    sums = np.zeros((counts.shape[0], pc.shape[1]), dtype=np.float64)
-    np.add.at(sums, inverse.reshape(-1), pc)
-    return sums / counts[:, None]
+    """Mean of the points inside every occupied voxel, voxels in lexicographic order of their integer
+    index ``floor((p - min) / voxel_size)`` (modules/icp.py:4-27).  On the device: float64 keys, stable
+    radix sort, one thread per voxel (the reference loops over voxels in Python, O(V·N))."""
+    pc = np.ascontiguousarray(point_cloud, dtype=np.float64)
+    if pc.ndim != 2 or pc.shape[1] not in (2, 3):
+        raise ValueError("point cloud must be (N,2) or (N,3)")
+    out = np.empty_like(pc)
+    count = np.zeros(1, dtype=np.int64)
+    check(lib().lslam_voxel_downsample(ptr(pc), pc.shape[0], pc.shape[1], float(voxel_size), ptr(out), ptr(count), _DEVICE))
+    return out[: int(count[0])].copy()
 
 
 def get_correspondences(pc1, pc2_tree):

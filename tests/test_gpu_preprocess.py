@@ -46,3 +46,21 @@ def test_random_scans_against_oracle_including_empty_and_large():
     exp = P.statistical_outliers_removal(z, 1.0)
     for a, b in zip(got, exp):
         np.testing.assert_array_equal(a, b)
+
+
+def test_voxel_downsample_matches_reference_and_oracle():
+    from lidar_slam_amd.modules import icp
+    from oracle import icp_oracle
+    g = golden("voxel.npz")
+    out = icp.voxel_downsample(g["points"], float(g["voxel_size"]))
+    assert out.shape == g["out"].shape
+    np.testing.assert_allclose(out, g["out"], rtol=0, atol=1e-14)          # same voxels, same order, same means
+    rng = np.random.default_rng(3)
+    for n, d, v in ((1, 3, 0.1), (50000, 3, 0.005), (30000, 2, 0.05), (7, 2, 10.0)):
+        pts = rng.normal(size=(n, d)) * 0.1
+        got = icp.voxel_downsample(pts, v)
+        exp = icp_oracle.voxel_downsample(pts, v)
+        assert got.shape == exp.shape
+        np.testing.assert_allclose(got, exp, rtol=0, atol=1e-14)
+    with pytest.raises(ValueError):
+        icp.voxel_downsample(rng.normal(size=(10, 3)) * 1e6, 1e-3)         # > 2^21 cells per axis
