@@ -26,6 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+LANE_OPS_PER_PAIR_EVAL = 4.86        # SQ_INSTS_VALU x 64 / pair evaluations of icp_batch_kernel<2,4> (profiles/r01/pmc_traffic.json)
 PEAK_FP32_VECTOR_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CUs × 4 SIMD × 32 lanes × 2 flop × 2.4 GHz
 PEAK_HBM_TBS = 8.0
 
@@ -184,6 +185,10 @@ def main():
         pair_evals_per_launch = float(S) * I * P * P
         flops = 5.0 * pair_evals_per_launch                        # 3d − 1 per pair evaluation, d = 2
         achieved = flops / (kernel_ms * 1e-3) / 1e12
+        import ctypes
+        probe = ctypes.c_double(0.0)
+        check(lib().lslam_valu_probe(local_rank, ctypes.byref(probe)))
+        issue_rate = probe.value                                   # lane-ops/s this device sustains under an all-VALU load
         result = {
             "metric": "icp_iterations_per_sec", "value": total_iters / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -197,6 +202,8 @@ def main():
                          "traffic": measured_traffic("c4") if (S, P, I) == (4096, 4096, 50) else None,
                          "kernel_ms": kernel_ms, "algorithmic_flop_per_pair_eval": 5,
                          "pair_evals_per_s": pair_evals_per_launch / (kernel_ms * 1e-3),
+                         "device_valu_issue_lane_ops_per_s": issue_rate, "kernel_lane_ops_per_pair_eval": LANE_OPS_PER_PAIR_EVAL,
+                         "frac_of_device_valu_issue_ceiling": pair_evals_per_launch / (kernel_ms * 1e-3) * LANE_OPS_PER_PAIR_EVAL / issue_rate,
                          "hbm_effective_untiled_TBps": pair_evals_per_launch * 8 / (kernel_ms * 1e-3) / 1e12,
                          "hbm_effective_frac_of_8TBps": pair_evals_per_launch * 8 / (kernel_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
                          "hbm_compulsory_bytes_per_launch": 2 * S * P * 8 + S * 2 * 128,

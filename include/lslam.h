@@ -49,6 +49,10 @@ int         lslam_device_count(void);
 /* bind the calling host thread to a device (one host thread / process per GPU) */
 int         lslam_set_device(int device);
 
+/* Measurement aid (no reference counterpart): the float32 VALU issue rate this device sustains
+ * under an all-VALU load, in lane-operations per second (≈ 10 ms of v_fma_f32 on every SIMD). */
+int         lslam_valu_probe(int device, double *out_lane_ops_per_s);
+
 /* ---- ICP: modules/icp.py:123-189 run_icp, batched ---------------------- */
 /*
  * S independent point-to-point ICP problems in one launch (one workgroup per

@@ -31,6 +31,7 @@ SIGNATURES = {
     "lslam_last_error": (C.c_char_p, []),
     "lslam_device_count": (C.c_int, []),
     "lslam_set_device": (C.c_int, [C.c_int]),
+    "lslam_valu_probe": (C.c_int, [C.c_int, C.c_void_p]),
     "lslam_icp_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_uint32, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

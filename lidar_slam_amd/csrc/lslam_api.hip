@@ -94,6 +94,7 @@ static IcpBatchTuning tuning_from_env() {
   if (const char* e = getenv("LSLAM_ICP_THREADS")) t.threads = atoi(e);
   if (const char* e = getenv("LSLAM_ICP_TILE_POINTS")) t.tile_points = atoi(e);
   if (const char* e = getenv("LSLAM_ICP_VARIANT")) t.variant = atoi(e);
+  if (const char* e = getenv("LSLAM_ICP_SRC_IN_LDS")) t.src_in_lds = atoi(e);
   return t;
 }
 
@@ -115,6 +116,20 @@ int lslam_device_count(void) {
 int lslam_set_device(int device) {
   clear_error();
   return use_device(device);
+}
+
+int lslam_valu_probe(int device, double* out_lane_ops_per_s) {
+  clear_error();
+  if (!out_lane_ops_per_s) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  int rc;
+  if ((rc = use_device(device)) != LSLAM_OK) return rc;
+  Arena& ar = thread_arena();
+  if ((rc = ar.reserve(device, sizeof(float) * 2048 * 256)) != LSLAM_OK) return rc;
+  float* d = static_cast<float*>(ar.carve(sizeof(float) * 2048 * 256));
+  hipStream_t st;
+  if ((rc = thread_stream(&st)) != LSLAM_OK) return rc;
+  LSLAM_HIP_TRY(run_valu_probe(d, st, out_lane_ops_per_s));
+  return LSLAM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------

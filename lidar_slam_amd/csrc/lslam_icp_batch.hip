@@ -103,7 +103,8 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
   constexpr int kAcc = AccLayout<DIM>::kTotal;
   extern __shared__ __align__(16) unsigned char smem[];
   TP* tile = reinterpret_cast<TP*>(smem);
-  double* sh_red = reinterpret_cast<double*>(smem + args.tile_bytes);        // [waves][kAcc]
+  float* sh_src = reinterpret_cast<float*>(smem + args.tile_bytes);           // the source cloud, DIM floats per point
+  double* sh_red = reinterpret_cast<double*>(smem + args.tile_bytes + args.src_bytes);   // [waves][kAcc]
   double* sh_T = sh_red + (size_t)kIcpBatchMaxWaves * kAcc;                   // current transform, 16
   int* sh_flag = reinterpret_cast<int*>(sh_T + 16);                           // [0] stop
 
@@ -127,6 +128,12 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
   const int ntiles = (m + tile_cap - 1) / tile_cap;
   const bool resident = (ntiles <= 1);                         // whole target stays in LDS
   if (resident) stage_tile<DIM>(gtgt, m, ((m + CHUNK - 1) / CHUNK) * CHUNK, tile);
+  // the source cloud is read every iteration (twice): keep it in LDS too when it fits, so that HBM/L2
+  // see each cloud exactly once per problem
+  const bool src_resident = (size_t)n * DIM * sizeof(float) <= args.src_bytes;
+  if (src_resident)
+    for (int i = tid; i < n * DIM; i += blockDim.x) sh_src[i] = gsrc[i];
+  const float* __restrict__ psrc = src_resident ? sh_src : gsrc;
   __syncthreads();
 
   StopState st;
@@ -148,10 +155,10 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
       double x = 0.0, y = 0.0, z = 0.0;
       if (i < n) {
         if constexpr (DIM == 2) {
-          const float2 v = *reinterpret_cast<const float2*>(gsrc + 2 * (int64_t)i);
+          const float2 v = *reinterpret_cast<const float2*>(psrc + 2 * (int64_t)i);
           x = v.x; y = v.y;
         } else {
-          x = gsrc[3 * (int64_t)i]; y = gsrc[3 * (int64_t)i + 1]; z = gsrc[3 * (int64_t)i + 2];
+          x = psrc[3 * (int64_t)i]; y = psrc[3 * (int64_t)i + 1]; z = psrc[3 * (int64_t)i + 2];
         }
       }
 #pragma unroll
@@ -217,10 +224,10 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
       if (i < n) {
         double x, y, z = 0.0;
         if constexpr (DIM == 2) {
-          const float2 v = *reinterpret_cast<const float2*>(gsrc + 2 * (int64_t)i);
+          const float2 v = *reinterpret_cast<const float2*>(psrc + 2 * (int64_t)i);
           x = v.x; y = v.y;
         } else {
-          x = gsrc[3 * (int64_t)i]; y = gsrc[3 * (int64_t)i + 1]; z = gsrc[3 * (int64_t)i + 2];
+          x = psrc[3 * (int64_t)i]; y = psrc[3 * (int64_t)i + 1]; z = psrc[3 * (int64_t)i + 2];
         }
         double pd[DIM], qd[DIM];
 #pragma unroll
@@ -362,7 +369,11 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
   a.tile_points = tile_points;
   a.tile_bytes = (uint32_t)(((size_t)tile_points * pt_bytes + 15) & ~(size_t)15);
   const int kAcc = (dim == 2) ? AccLayout<2>::kTotal : AccLayout<3>::kTotal;
-  const size_t smem = a.tile_bytes + sizeof(double) * ((size_t)kIcpBatchMaxWaves * kAcc + 16) + 16;
+  // keep the source cloud in LDS as well while two (big build) / four (small build) workgroups still fit a CU
+  const size_t budget = small ? 36 * 1024 : 72 * 1024;
+  const size_t src_need = (((size_t)max_src_n * dim * sizeof(float)) + 15) & ~(size_t)15;
+  a.src_bytes = (a.tile_bytes + src_need <= budget && tune.src_in_lds != 2) || tune.src_in_lds == 1 ? (uint32_t)src_need : 0u;
+  const size_t smem = a.tile_bytes + a.src_bytes + sizeof(double) * ((size_t)kIcpBatchMaxWaves * kAcc + 16) + 16;
 
   if (dim == 2) {
     if (P == 1) return launch_one<2, 1>(a, S, threads, smem, small, stream);

@@ -41,6 +41,7 @@ struct IcpBatchArgs {
   uint32_t flags;
   int32_t tile_points;       // filled by the launcher
   uint32_t tile_bytes;       // filled by the launcher
+  uint32_t src_bytes;        // filled by the launcher: LDS reserved for the source cloud (0 = read it from memory)
 };
 
 struct IcpBatchTuning {
@@ -48,6 +49,7 @@ struct IcpBatchTuning {
   int threads = 0;           // 0 = from max_src_n
   int tile_points = 0;       // 0 = default cap
   int variant = 0;           // 0 = automatic, 1 = force the 128-VGPR build, 2 = force the 64-VGPR build
+  int src_in_lds = 0;        // 0 = automatic, 1 = always, 2 = never
 };
 
 hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, int64_t max_tgt_n,
@@ -127,6 +129,7 @@ struct PairOpArgs {
   double* out_err;         // device, 1 double (or nullptr)
 };
 hipError_t launch_pair_op(const PairOpArgs& a, hipStream_t stream);
+hipError_t run_valu_probe(float* d_scratch, hipStream_t stream, double* lane_ops_per_s);
 
 // ---- occupancy grid (lslam_ogm.hip) -----------------------------------------------------------------
 constexpr int kOgmPlanes = 32;   // scans traced per launch, each into its own int32 count plane

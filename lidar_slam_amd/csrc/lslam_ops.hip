@@ -45,6 +45,44 @@ pair_op_kernel(PairOpArgs a) {
   }
 }
 
+// ---- device probe: sustained float32 VALU issue rate --------------------------------------------
+// 64 independent-enough v_fma_f32 per loop trip on every SIMD of the chip.  The ICP search kernels
+// are bound by VALU issue slots at whatever clock the chip sustains under an all-VALU load (≈1.9 GHz,
+// it varies by a few percent from device to device); bench.py prices them against this measurement
+// as well as against the 2.4 GHz datasheet peak.
+__global__ void __launch_bounds__(256) valu_probe_kernel(float* out, int iters, float seed) {
+  float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  const float b = 1.0001f, c = 0.5f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c); a2 = __builtin_fmaf(a2, b, c); a3 = __builtin_fmaf(a3, b, c);
+      a4 = __builtin_fmaf(a4, b, c); a5 = __builtin_fmaf(a5, b, c); a6 = __builtin_fmaf(a6, b, c); a7 = __builtin_fmaf(a7, b, c);
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+hipError_t run_valu_probe(float* d_scratch /*2048*256 floats*/, hipStream_t stream, double* lane_ops_per_s) {
+  const int blocks = 2048, threads = 256, iters = 12000;
+  hipEvent_t e0, e1;
+  hipError_t e;
+  if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
+  if ((e = hipEventCreate(&e1)) != hipSuccess) return e;
+  hipLaunchKernelGGL(valu_probe_kernel, dim3(blocks), dim3(threads), 0, stream, d_scratch, 2000, 1.0f);   // ramp the clocks
+  (void)hipEventRecord(e0, stream);
+  hipLaunchKernelGGL(valu_probe_kernel, dim3(blocks), dim3(threads), 0, stream, d_scratch, iters, 1.0f);
+  (void)hipEventRecord(e1, stream);
+  e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return e;
+  *lane_ops_per_s = (double)blocks * threads * (double)iters * 64.0 / (ms * 1e-3);
+  return hipSuccess;
+}
+
 hipError_t launch_pair_op(const PairOpArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(pair_op_kernel, dim3(1), dim3(kPairOpThreads), 0, stream, a);
   return hipGetLastError();
