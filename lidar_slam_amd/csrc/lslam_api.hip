@@ -173,6 +173,12 @@ int lslam_icp_batch(const float* src, const int64_t* src_off, const float* tgt, 
   if (!all_finite(src + dim * src_off[0], dim * (tot_n - src_off[0])) ||
       !all_finite(tgt + dim * tgt_off[0], dim * (tot_m - tgt_off[0])))
     return fail(LSLAM_ERR_NONFINITE, "point clouds must be finite (NaN or Inf found)");
+  if (dim == 2)                                           // the planar kernels never materialise z
+    for (int32_t s = 0; s < S; ++s) {
+      const double* T = init_T + 16 * (size_t)s;
+      if (T[8] != 0.0 || T[9] != 0.0 || T[11] != 0.0)
+        return fail(LSLAM_ERR_BAD_ARG, "problem %d: init_T moves planar points out of the z = 0 plane; pass the clouds as (n,3)", s);
+    }
   if ((rc = use_device(device)) != LSLAM_OK) return rc;
 
   const bool shared = (src == tgt);                       // scan sequence: upload the scans once

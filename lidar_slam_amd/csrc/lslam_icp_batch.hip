@@ -54,24 +54,36 @@ __device__ __forceinline__ void sweep_tile(const typename TilePoint<DIM>::type* 
                                            int chunk_base, const float (&a)[P][DIM],
                                            float (&best)[P], int (&bchunk)[P]) {
   if constexpr (DIM == 2) {
+    // a record step (min, chunk id) covers CHUNK targets; they are loaded LOAD at a time so that a
+    // 32-target chunk does not need 64 registers of target data
+    constexpr int LOAD = CHUNK > 16 ? 16 : CHUNK;
     const float4* t4 = reinterpret_cast<const float4*>(tile);    // two planar points per 16 B
     for (int c = 0; c < nchunks; ++c) {
-      float4 v[CHUNK / 2];
+      float m[P];
 #pragma unroll
-      for (int k = 0; k < CHUNK / 2; ++k) v[k] = t4[c * (CHUNK / 2) + k];
+      for (int h = 0; h < CHUNK / LOAD; ++h) {
+        float4 v[LOAD / 2];
+#pragma unroll
+        for (int k = 0; k < LOAD / 2; ++k) v[k] = t4[c * (CHUNK / 2) + h * (LOAD / 2) + k];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const float e0 = dist2(a[p][0], a[p][1], v[0].x, v[0].y);
+          const float e1 = dist2(a[p][0], a[p][1], v[0].z, v[0].w);
+          float mm = (h == 0) ? fminf(e0, e1) : fminf(fminf(e0, e1), m[p]);
+#pragma unroll
+          for (int k = 1; k < LOAD / 2; ++k) {
+            const float d0 = dist2(a[p][0], a[p][1], v[k].x, v[k].y);
+            const float d1 = dist2(a[p][0], a[p][1], v[k].z, v[k].w);
+            mm = fminf(fminf(d0, d1), mm);
+          }
+          m[p] = mm;
+        }
+      }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        float m = dist2(a[p][0], a[p][1], v[0].x, v[0].y);
-        m = fminf(m, dist2(a[p][0], a[p][1], v[0].z, v[0].w));
-#pragma unroll
-        for (int k = 1; k < CHUNK / 2; ++k) {
-          const float d0 = dist2(a[p][0], a[p][1], v[k].x, v[k].y);
-          const float d1 = dist2(a[p][0], a[p][1], v[k].z, v[k].w);
-          m = fminf(fminf(d0, d1), m);
-        }
-        const bool lt = m < best[p];
+        const bool lt = m[p] < best[p];
         bchunk[p] = lt ? (chunk_base + c) : bchunk[p];
-        best[p] = fminf(best[p], m);
+        best[p] = fminf(best[p], m[p]);
       }
     }
   } else {
@@ -362,7 +374,7 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
   const int pt_bytes = (dim == 2) ? 8 : 16;
   int cap = (dim == 2) ? kIcpTileMaxPlanar : kIcpTileMax3D;
   if (tune.tile_points > 0) cap = tune.tile_points;
-  cap = ((cap + 15) / 16) * 16;                              // a multiple of every chunk size
+  cap = ((cap + 31) / 32) * 32;                              // a multiple of every chunk size
   int64_t need = ((max_tgt_n + CHUNK - 1) / CHUNK) * CHUNK;
   if (need < CHUNK) need = CHUNK;
   const int tile_points = (int)(need < cap ? need : cap);

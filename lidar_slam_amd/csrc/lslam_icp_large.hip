@@ -26,7 +26,7 @@ constexpr unsigned long long kKeyInit = ~0ull;
 template <int DIM, int P>
 __global__ void __launch_bounds__(kNnThreads)
 nn_tiled_kernel(NnArgs a) {
-  constexpr int CHUNK = IcpChunk<DIM>::value;
+  constexpr int CHUNK = NnChunk<DIM>::value;
   using TP = typename std::conditional<DIM == 2, float2, float4>::type;
   extern __shared__ __align__(16) unsigned char smem[];
   TP* tile = reinterpret_cast<TP*>(smem);
@@ -276,7 +276,7 @@ solve_kernel(SolveArgs a) {
 // ---- launchers -----------------------------------------------------------------------------------
 NnGeometry nn_geometry(int dim, int64_t n, int64_t m) {
   NnGeometry g{};
-  const int CHUNK = (dim == 2) ? IcpChunk<2>::value : IcpChunk<3>::value;
+  const int CHUNK = (dim == 2) ? NnChunk<2>::value : NnChunk<3>::value;
   const int pt_bytes = (dim == 2) ? 8 : 16;
   g.P = (n >= 65536) ? 4 : (n >= 8192 ? 2 : 1);
   const int64_t per_block = (int64_t)kNnThreads * g.P;

@@ -15,7 +15,7 @@ constexpr uint32_t kFlagNormalize = 1u;   // == LSLAM_ICP_NORMALIZE_ERROR
 
 // targets examined per (min, chunk-id) record; the fix-up pass re-evaluates one chunk per source
 template <int DIM> struct IcpChunk;
-template <> struct IcpChunk<2> { static constexpr int value = 16; };
+template <> struct IcpChunk<2> { static constexpr int value = 16; };   // 32 (two loads per record step) measured slower: the 32-point fix-up spills
 template <> struct IcpChunk<3> { static constexpr int value = 8; };
 // the 64-VGPR build for LiDAR-sized problems keeps fewer target points in registers
 template <int DIM> struct IcpChunkSmall;
@@ -56,6 +56,10 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
                             const IcpBatchTuning& tune, hipStream_t stream);
 
 // ---- one large pair (lslam_icp_large.hip) ---------------------------------------------------------
+// chunk of the whole-chip search kernel (its planar sweep keeps a whole chunk in registers)
+template <int DIM> struct NnChunk;
+template <> struct NnChunk<2> { static constexpr int value = 16; };
+template <> struct NnChunk<3> { static constexpr int value = 8; };
 constexpr int kNnThreads = 256;
 constexpr int kNnTilePlanar = 4096;   // 32 KiB of LDS per workgroup → 4 workgroups per CU
 constexpr int kNnTile3D = 2048;       // 32 KiB

@@ -47,6 +47,9 @@ def test_argument_validation_needs_no_gpu():
         icp_batch(bad, off, pts, off, np.eye(4)[None])
     with pytest.raises(ValueError):
         icp_batch(np.zeros((4, 5), np.float32), off, pts, off, np.eye(4)[None])
+    tilt = np.eye(4); tilt[2, 0] = 0.1                    # would lift planar points out of z = 0
+    with pytest.raises(ValueError):
+        icp_batch(pts + 1, off, pts + 1, off, tilt[None])
 
 
 def test_no_silent_cpu_fallback_without_a_device():
