@@ -185,6 +185,31 @@ int lslam_lidar_preprocess(uint32_t stages,
                            double eps, int32_t min_samples, double k_std,
                            double *out_xy, int64_t *out_off, double *out_stats, int device);
 
+/* ---- device-resident scan sets ---------------------------------------------------------- */
+/*
+ * The reference hands the scans from stage to stage as a Python list (main.py:84-87 -> :120 -> :205).
+ * A scan set keeps them in HBM instead: created from raw ranges or from points (optionally through the
+ * pre-processing stages above), then consumed by scan matching and by the occupancy grid without
+ * returning to the host.  It holds the points as float64 (ray casting) and float32 (ICP) plus offsets.
+ */
+int lslam_scans_create(uint32_t stages,
+                       const double *ranges, int32_t K, int32_t B,
+                       const double *cos_a, const double *sin_a, double off_x, double off_y,
+                       double range_min, double range_max,
+                       const double *in_xy, const int64_t *in_off,
+                       double eps, int32_t min_samples, double k_std,
+                       double *out_stats, int device, void **out_handle);
+int lslam_scans_destroy(void *scans);
+/* K scans, total points, largest scan */
+int lslam_scans_info(void *scans, int64_t *K, int64_t *total_points, int64_t *max_points);
+/* copy to the host: out_xy (total x 2 float64, may be NULL), out_off (K+1) */
+int lslam_scans_download(void *scans, double *out_xy, int64_t *out_off);
+/* poses_from_scan_matching's ICP batch (localization.py:115-124) on the resident scans: problem s aligns
+ * scan s+1 (source) to scan s (target); init_T / out_*: HOST, S = K-1 problems. */
+int lslam_scans_match_sequence(void *scans, const double *init_T,
+                               double epsilon, double stopping_thresh, int32_t max_iters, uint32_t flags,
+                               double *out_T, double *out_err, int32_t *out_iters);
+
 /* ---- occupancy grid: modules/ogm.py ------------------------------------- */
 /* OccupancyGridMap state (ogm.py:37-43) resident in HBM: float32 log-odds
  * (width x height, indexed [x_cell][y_cell], ogm.py:41) plus an int32 hit/miss
@@ -201,6 +226,9 @@ int lslam_ogm_set_params(void *handle, double logodds_step, double logodds_clip)
  * float64 robot-frame points scans_xy[scan_off[k] .. scan_off[k+1]).  HOST pointers. */
 int lslam_ogm_update(void *handle, const double *poses, const double *scans_xy,
                      const int64_t *scan_off, int32_t K);
+
+/* Same with the scans of a device-resident scan set (poses: K x 3, HOST). */
+int lslam_ogm_update_scans(void *handle, void *scans, const double *poses);
 
 /* The integer (hits - misses) grid ONE scan would add, without touching the
  * log-odds: the bit-exact contract for cell indices (ogm.py:169-185).  out: width*height int32. */

@@ -56,6 +56,15 @@ SIGNATURES = {
     "lslam_lidar_preprocess": (C.c_int, [C.c_uint32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
                                          C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_double,
                                          C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "lslam_scans_create": (C.c_int, [C.c_uint32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
+                                     C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_double, C.c_int32,
+                                     C.c_double, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "lslam_scans_destroy": (C.c_int, [C.c_void_p]),
+    "lslam_scans_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "lslam_scans_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lslam_scans_match_sequence": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_uint32,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lslam_ogm_update_scans": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "lslam_ogm_create": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double,
                                    C.c_double, C.c_int, C.POINTER(C.c_void_p)]),
     "lslam_ogm_destroy": (C.c_int, [C.c_void_p]),

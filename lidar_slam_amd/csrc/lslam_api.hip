@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -506,14 +507,17 @@ int lslam_chain_se2(const double* rel, int64_t S, double* out) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-int lslam_lidar_preprocess(uint32_t stages, const double* ranges, int32_t K, int32_t B, const double* cos_a,
+// Shared by lslam_lidar_preprocess (results to the host) and lslam_scans_create (results stay on the
+// device): runs the selected stages; out_off (host, K+1) is always filled; the final points are copied
+// to out_xy if it is non-null; *d_final / *st_out expose the device copy (valid until the thread's
+// arena is reused) and the stream it was produced on.
+static int preprocess_core(uint32_t stages, const double* ranges, int32_t K, int32_t B, const double* cos_a,
                            const double* sin_a, double off_x, double off_y, double range_min, double range_max,
                            const double* in_xy, const int64_t* in_off, double eps, int32_t min_samples, double k_std,
-                           double* out_xy, int64_t* out_off, double* out_stats, int device) {
-  clear_error();
+                           double* out_xy, int64_t* out_off, double* out_stats, int device, bool need_host_xy,
+                           const double** d_final, hipStream_t* st_out) {
   if (K < 0) return fail(LSLAM_ERR_BAD_ARG, "negative scan count");
   if (!out_off) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
-  if (!(stages & (LSLAM_PRE_POLAR | LSLAM_PRE_DBSCAN | LSLAM_PRE_RADIAL))) return fail(LSLAM_ERR_BAD_ARG, "no stage selected");
   const bool polar = (stages & LSLAM_PRE_POLAR) != 0;
   int64_t total = 0, max_n = 0;
   if (polar) {
@@ -531,12 +535,14 @@ int lslam_lidar_preprocess(uint32_t stages, const double* ranges, int32_t K, int
     total = in_off[K];
     if (total > 0 && !in_xy) return fail(LSLAM_ERR_BAD_ARG, "null input points");
   }
+  if (d_final) *d_final = nullptr;
   if (K == 0) { out_off[0] = 0; return LSLAM_OK; }
-  if (total > 0 && !out_xy) return fail(LSLAM_ERR_BAD_ARG, "null output buffer");
+  if (need_host_xy && total > 0 && !out_xy) return fail(LSLAM_ERR_BAD_ARG, "null output buffer");
   int rc;
   if ((rc = use_device(device)) != LSLAM_OK) return rc;
   hipStream_t st;
   if ((rc = thread_stream(&st)) != LSLAM_OK) return rc;
+  if (st_out) *st_out = st;
 
   // device scratch: two point buffers (ping-pong), two offset arrays, masks, counts, statistics
   const size_t nb = (size_t)(B > 0 ? B : 1);
@@ -586,14 +592,33 @@ int lslam_lidar_preprocess(uint32_t stages, const double* ranges, int32_t K, int
   }
   LSLAM_HIP_TRY(hipMemcpyAsync(out_off, d_off[cur], b_off, hipMemcpyDeviceToHost, st));
   LSLAM_HIP_TRY(hipStreamSynchronize(st));
-  if (out_off[K] > 0)
+  if (need_host_xy && out_off[K] > 0)
     LSLAM_HIP_TRY(hipMemcpy(out_xy, d_pts[cur], sizeof(double) * 2 * (size_t)out_off[K], hipMemcpyDeviceToHost));
+  if (d_final) *d_final = d_pts[cur];
   return LSLAM_OK;
+}
+
+int lslam_lidar_preprocess(uint32_t stages, const double* ranges, int32_t K, int32_t B, const double* cos_a,
+                           const double* sin_a, double off_x, double off_y, double range_min, double range_max,
+                           const double* in_xy, const int64_t* in_off, double eps, int32_t min_samples, double k_std,
+                           double* out_xy, int64_t* out_off, double* out_stats, int device) {
+  clear_error();
+  if (!(stages & (LSLAM_PRE_POLAR | LSLAM_PRE_DBSCAN | LSLAM_PRE_RADIAL))) return fail(LSLAM_ERR_BAD_ARG, "no stage selected");
+  return preprocess_core(stages, ranges, K, B, cos_a, sin_a, off_x, off_y, range_min, range_max, in_xy, in_off, eps,
+                         min_samples, k_std, out_xy, out_off, out_stats, device, true, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
 extern "C++" {
 namespace {
+struct ScanSet {
+  int device = 0;
+  int64_t K = 0, total = 0, max_n = 0;
+  double* d_xy64 = nullptr;
+  float* d_xy32 = nullptr;
+  int64_t* d_off = nullptr;
+  std::vector<int64_t> h_off;
+};
 struct Ogm {
   OgmGrid g{};
   int device = 0;
@@ -615,6 +640,115 @@ int ogm_scan_buffer(Ogm* o, int64_t points) {
 }
 }  // namespace
 }  // extern "C++"
+
+int lslam_scans_destroy(void* scans) {
+  if (!scans) return LSLAM_OK;
+  ScanSet* z = static_cast<ScanSet*>(scans);
+  (void)hipSetDevice(z->device);
+  if (z->d_xy64) (void)hipFree(z->d_xy64);
+  if (z->d_xy32) (void)hipFree(z->d_xy32);
+  if (z->d_off) (void)hipFree(z->d_off);
+  delete z;
+  return LSLAM_OK;
+}
+
+int lslam_scans_create(uint32_t stages, const double* ranges, int32_t K, int32_t B, const double* cos_a,
+                       const double* sin_a, double off_x, double off_y, double range_min, double range_max,
+                       const double* in_xy, const int64_t* in_off, double eps, int32_t min_samples, double k_std,
+                       double* out_stats, int device, void** out_handle) {
+  clear_error();
+  if (!out_handle) return fail(LSLAM_ERR_BAD_ARG, "null handle pointer");
+  *out_handle = nullptr;
+  if (K < 0) return fail(LSLAM_ERR_BAD_ARG, "negative scan count");
+  ScanSet* z = new (std::nothrow) ScanSet();
+  if (!z) return fail(LSLAM_ERR_BAD_ARG, "out of host memory");
+  z->device = device;
+  z->K = K;
+  z->h_off.assign((size_t)K + 1, 0);
+  const double* d_final = nullptr;
+  hipStream_t st = nullptr;
+  int rc = preprocess_core(stages, ranges, K, B, cos_a, sin_a, off_x, off_y, range_min, range_max, in_xy, in_off, eps,
+                           min_samples, k_std, nullptr, z->h_off.data(), out_stats, device, false, &d_final, &st);
+  if (rc != LSLAM_OK) { delete z; return rc; }
+  z->total = z->h_off[(size_t)K];
+  for (int64_t k = 0; k < K; ++k) z->max_n = std::max(z->max_n, z->h_off[(size_t)k + 1] - z->h_off[(size_t)k]);
+  hipError_t e = hipSuccess;
+  const size_t pts = (size_t)(z->total > 0 ? z->total : 1);
+  if ((e = hipMalloc(&z->d_xy64, sizeof(double) * 2 * pts)) != hipSuccess ||
+      (e = hipMalloc(&z->d_xy32, sizeof(float) * 2 * pts)) != hipSuccess ||
+      (e = hipMalloc(&z->d_off, sizeof(int64_t) * ((size_t)K + 1))) != hipSuccess) {
+    lslam_scans_destroy(z);
+    return fail(LSLAM_ERR_HIP, "scan set allocation failed: %s", hipGetErrorString(e));
+  }
+  if (K > 0) {
+    if (z->total > 0) {
+      e = hipMemcpyAsync(z->d_xy64, d_final, sizeof(double) * 2 * (size_t)z->total, hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = launch_f64_to_f32(z->d_xy64, z->d_xy32, 2 * z->total, st);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(z->d_off, z->h_off.data(), sizeof(int64_t) * ((size_t)K + 1), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { lslam_scans_destroy(z); return fail(LSLAM_ERR_HIP, "scan set upload failed: %s", hipGetErrorString(e)); }
+  }
+  *out_handle = z;
+  return LSLAM_OK;
+}
+
+int lslam_scans_info(void* scans, int64_t* K, int64_t* total_points, int64_t* max_points) {
+  clear_error();
+  if (!scans) return fail(LSLAM_ERR_BAD_ARG, "null handle");
+  ScanSet* z = static_cast<ScanSet*>(scans);
+  if (K) *K = z->K;
+  if (total_points) *total_points = z->total;
+  if (max_points) *max_points = z->max_n;
+  return LSLAM_OK;
+}
+
+int lslam_scans_download(void* scans, double* out_xy, int64_t* out_off) {
+  clear_error();
+  if (!scans || !out_off) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  ScanSet* z = static_cast<ScanSet*>(scans);
+  LSLAM_HIP_TRY(hipSetDevice(z->device));
+  memcpy(out_off, z->h_off.data(), sizeof(int64_t) * ((size_t)z->K + 1));
+  if (out_xy && z->total > 0) LSLAM_HIP_TRY(hipMemcpy(out_xy, z->d_xy64, sizeof(double) * 2 * (size_t)z->total, hipMemcpyDeviceToHost));
+  return LSLAM_OK;
+}
+
+int lslam_scans_match_sequence(void* scans, const double* init_T, double epsilon, double stopping_thresh,
+                               int32_t max_iters, uint32_t flags, double* out_T, double* out_err, int32_t* out_iters) {
+  clear_error();
+  if (!scans) return fail(LSLAM_ERR_BAD_ARG, "null handle");
+  ScanSet* z = static_cast<ScanSet*>(scans);
+  const int64_t S = z->K - 1;
+  if (S <= 0) return LSLAM_OK;
+  if (S > 0x7fffffff) return fail(LSLAM_ERR_BAD_ARG, "too many scans");
+  if (!init_T || !out_T || !out_err || !out_iters) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  for (int64_t s = 0; s < S; ++s) {
+    if (z->h_off[(size_t)s + 1] == z->h_off[(size_t)s]) return fail(LSLAM_ERR_EMPTY_TARGET, "problem %lld has an empty target cloud", (long long)s);
+    const double* T = init_T + 16 * (size_t)s;
+    if (T[8] != 0.0 || T[9] != 0.0 || T[11] != 0.0) return fail(LSLAM_ERR_BAD_ARG, "problem %lld: init_T leaves the z = 0 plane", (long long)s);
+  }
+  int rc;
+  if ((rc = use_device(z->device)) != LSLAM_OK) return rc;
+  const size_t b_T = sizeof(double) * 16 * (size_t)S;
+  Arena& ar = thread_arena();
+  if ((rc = ar.reserve(z->device, 2 * Arena::align(b_T) + Arena::align(sizeof(double) * S) + Arena::align(sizeof(int32_t) * S))) != LSLAM_OK) return rc;
+  double* d_iT = static_cast<double*>(ar.carve(b_T));
+  double* d_oT = static_cast<double*>(ar.carve(b_T));
+  double* d_err = static_cast<double*>(ar.carve(sizeof(double) * S));
+  int32_t* d_it = static_cast<int32_t*>(ar.carve(sizeof(int32_t) * S));
+  hipStream_t st;
+  if ((rc = thread_stream(&st)) != LSLAM_OK) return rc;
+  LSLAM_HIP_TRY(hipMemcpyAsync(d_iT, init_T, b_T, hipMemcpyHostToDevice, st));
+  // source = scan s+1, target = scan s (localization.py:120-121): the same buffer with shifted offsets
+  rc = lslam_icp_batch_dev(z->d_xy32, z->d_off + 1, z->d_xy32, z->d_off, 2, d_iT, (int32_t)S, z->max_n, z->max_n, epsilon,
+                           stopping_thresh, max_iters, flags, d_oT, d_err, d_it, nullptr, st);
+  if (rc != LSLAM_OK) return rc;
+  LSLAM_HIP_TRY(hipMemcpyAsync(out_T, d_oT, b_T, hipMemcpyDeviceToHost, st));
+  LSLAM_HIP_TRY(hipMemcpyAsync(out_err, d_err, sizeof(double) * S, hipMemcpyDeviceToHost, st));
+  LSLAM_HIP_TRY(hipMemcpyAsync(out_iters, d_it, sizeof(int32_t) * S, hipMemcpyDeviceToHost, st));
+  LSLAM_HIP_TRY(hipStreamSynchronize(st));
+  return LSLAM_OK;
+}
 
 int lslam_ogm_create(double res, double world_min_x, double world_min_y, int32_t width, int32_t height,
                      double logodds_step, double logodds_clip, int device, void** out_handle) {
@@ -720,6 +854,20 @@ int lslam_ogm_update(void* handle, const double* poses, const double* scans_xy, 
     LSLAM_HIP_TRY(hipMemcpyAsync(o->d_scan, scans_xy + 2 * first, sizeof(double) * 2 * (size_t)total, hipMemcpyHostToDevice, o->stream));
   }
   if ((rc = ogm_enqueue(o, poses, o->d_scan, scan_off, first, K, true)) != LSLAM_OK) return rc;
+  LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+  return LSLAM_OK;
+}
+
+int lslam_ogm_update_scans(void* handle, void* scans, const double* poses) {
+  clear_error();
+  if (!handle || !scans || !poses) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  Ogm* o = static_cast<Ogm*>(handle);
+  ScanSet* z = static_cast<ScanSet*>(scans);
+  if (o->device != z->device) return fail(LSLAM_ERR_BAD_ARG, "grid and scan set live on different devices");
+  if (z->K > 0x7fffffff) return fail(LSLAM_ERR_BAD_ARG, "too many scans");
+  LSLAM_HIP_TRY(hipSetDevice(o->device));
+  int rc;
+  if ((rc = ogm_enqueue(o, poses, z->d_xy64, z->h_off.data(), 0, (int32_t)z->K, true)) != LSLAM_OK) return rc;
   LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
   return LSLAM_OK;
 }

@@ -166,6 +166,7 @@ hipError_t launch_dbscan_mask(const double* xy, const int64_t* off, int32_t K, i
                               uint8_t* core, uint8_t* keep, int32_t* counts, hipStream_t st);
 hipError_t launch_radial_mask(const double* xy, const int64_t* off, int32_t K, int64_t total, double k_std, double* partial,
                               double* stats, uint8_t* keep, int32_t* counts, hipStream_t st);
+hipError_t launch_f64_to_f32(const double* in, float* out, int64_t n, hipStream_t st);
 hipError_t launch_compact(const double* xy, const int64_t* in_off, int32_t B, const uint8_t* keep, const int32_t* counts,
                           int32_t K, int64_t* out_off, double* out_xy, hipStream_t st);
 

@@ -232,6 +232,16 @@ compact_scatter_kernel(const double* __restrict__ xy, const int64_t* __restrict_
   }
 }
 
+__global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+hipError_t launch_f64_to_f32(const double* in, float* out, int64_t n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+  return hipGetLastError();
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------
 hipError_t launch_polar_mask(const double* ranges, int32_t K, int32_t B, const double* cos_a, const double* sin_a,
                              double off_x, double off_y, double rmin, double rmax, double* xy_full, uint8_t* keep,

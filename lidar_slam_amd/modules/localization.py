@@ -49,6 +49,13 @@ def scan_matching_relative_poses(x_ts, z_ts, device=0, return_info=False):
     S = x_ts.shape[0] - 1
     if len(z_ts) != S + 1:
         raise ValueError("need one scan per pose")
+    from ..scans import ScanSet
+    if isinstance(z_ts, ScanSet):                      # points already in HBM: no packing, no upload
+        r = z_ts.match_sequence(relative_pose_guesses(x_ts), epsilon=0.001)
+        rel = np.tile(np.eye(3), (S, 1, 1))
+        rel[:, :2, :2] = r.T[:, :2, :2]
+        rel[:, :2, 2] = r.T[:, :2, 3]
+        return (rel, r) if return_info else rel
     pts, off = pack_clouds(z_ts if isinstance(z_ts, PackedScans) else [np.asarray(z) for z in z_ts])
     if pts.shape[1] != 2:
         raise ValueError("scans must be (n_i, 2) robot-frame points")
@@ -122,11 +129,18 @@ def _pack64(z_ts):
 
 
 def preprocess_lidar(lidar_ranges=None, lidar_range_min=0.1, lidar_range_max=30.0, z_ts=None, dbscan=None,
-                     k_std=None, device=0, return_stats=False):
+                     k_std=None, device=0, return_stats=False, resident=False):
     """The whole chain of main.py:84-87 in one library call, intermediate results staying on the GPU:
     ``get_lidar_data`` (when ``lidar_ranges`` (K, B) is given, else start from ``z_ts``) →
     ``DBSCAN_outliers_removal`` (``dbscan=(eps, min_samples)``) → ``statistical_outliers_removal``
-    (``k_std``).  Returns the list of (n_k, 2) float64 scans [, (mean, std, threshold)]."""
+    (``k_std``).  Returns the list of (n_k, 2) float64 scans [, (mean, std, threshold)]; with
+    ``resident=True`` a :class:`lidar_slam_amd.scans.ScanSet` whose points never leave the device
+    unless they are read."""
+    if resident:
+        from ..scans import ScanSet
+        zs = (ScanSet.from_ranges(lidar_ranges, lidar_range_min, lidar_range_max, dbscan, k_std, device)
+              if lidar_ranges is not None else ScanSet.from_scans(z_ts, dbscan, k_std, device))
+        return (zs, zs.stats) if return_stats else zs
     from .. import _lib
     from .._lib import check, lib, ptr
     stages = 0

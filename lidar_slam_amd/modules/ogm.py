@@ -84,6 +84,16 @@ class OccupancyGridMap:
         states = np.ascontiguousarray(np.asarray(states, dtype=np.float64)[:, :3])
         K = states.shape[0]
         from ..batch import PackedScans
+        from ..scans import ScanSet
+        if isinstance(meas, ScanSet):                   # scans already in HBM
+            if len(meas) != K:
+                raise ValueError("need one scan per state")
+            check(lib().lslam_ogm_update_scans(self._handle, meas._handle, ptr(states)))
+            self._host_stale = True
+            out = np.empty(self._shape, dtype=np.uint8)
+            check(lib().lslam_ogm_binarize(self._handle, ptr(out)))
+            self.grid_map = out
+            return
         if isinstance(meas, PackedScans) and len(meas) == K and meas.flat.dtype == np.float64:
             flat, off = np.ascontiguousarray(meas.flat), meas.off          # already packed: no copies
         else:

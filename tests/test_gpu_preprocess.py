@@ -64,3 +64,28 @@ def test_voxel_downsample_matches_reference_and_oracle():
         np.testing.assert_allclose(got, exp, rtol=0, atol=1e-14)
     with pytest.raises(ValueError):
         icp.voxel_downsample(rng.normal(size=(10, 3)) * 1e6, 1e-3)         # > 2^21 cells per axis
+
+
+def test_resident_scan_set_pipeline_equals_host_pipeline():
+    """ranges → filters → scan matching → occupancy grid with the scans staying in HBM gives exactly
+    what the stage-by-stage host-array path gives"""
+    from lidar_slam_amd.modules import localization as L
+    from lidar_slam_amd.modules.ogm import OccupancyGridMap
+    from lidar_slam_amd import synth
+    seq = synth.sequence_c3(80, seed=3, drop=(0.0, 0.05), half=4.5, n_obstacles=6)
+    host = L.preprocess_lidar(seq.ranges, 0.1, 30.0, dbscan=(0.1, 10), k_std=2)
+    dev, stats = L.preprocess_lidar(seq.ranges, 0.1, 30.0, dbscan=(0.1, 10), k_std=2, resident=True, return_stats=True)
+    assert len(dev) == len(host) == 80 and dev.n_points == sum(z.shape[0] for z in host)
+    poses_h, rel_h = L.poses_from_scan_matching(seq.x_ts, host, return_relative_poses=True)
+    poses_d, rel_d = L.poses_from_scan_matching(seq.x_ts, dev, return_relative_poses=True)
+    np.testing.assert_array_equal(rel_d, rel_h)
+    np.testing.assert_array_equal(poses_d, poses_h)
+    gh, gd = OccupancyGridMap(0.05, 10, 10, -10, -10), OccupancyGridMap(0.05, 10, 10, -10, -10)
+    gh.build_map(poses_h, host)
+    gd.build_map(poses_d, dev)
+    np.testing.assert_array_equal(gd.grid_map_log_odds, gh.grid_map_log_odds)
+    np.testing.assert_array_equal(gd.grid_map, gh.grid_map)
+    for a, b in zip(dev, host):                         # reading the set downloads the same points
+        np.testing.assert_array_equal(a, b)
+    plain = L.preprocess_lidar(z_ts=[np.asarray(z) for z in host], resident=True)      # no stage: just upload
+    np.testing.assert_array_equal(plain[7], host[7])
