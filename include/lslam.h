@@ -76,6 +76,11 @@ int         lslam_valu_probe(int device, double *out_lane_ops_per_s);
  *   flags      LSLAM_ICP_* bits
  */
 #define LSLAM_ICP_NORMALIZE_ERROR 1u   /* icp.py:91-97 */
+/* Opt-in (planar problems of at most 4096 points per cloud; ignored otherwise): put both clouds into
+ * Morton order once per problem and skip, with an exact float32-safe bound, every 16-point target
+ * chunk that cannot hold a nearer point for any source of a wave.  Same correspondences, iteration
+ * counts and (to float64 summation order) transforms as the plain all-pairs sweep. */
+#define LSLAM_ICP_PRUNE 2u
 
 int lslam_icp_batch(const float *src, const int64_t *src_off,
                     const float *tgt, const int64_t *tgt_off,

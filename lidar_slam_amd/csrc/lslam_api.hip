@@ -151,6 +151,32 @@ int lslam_icp_batch_dev(const float* d_src, const int64_t* d_src_off, const floa
   a.init_T = d_init_T; a.out_T = d_out_T; a.out_err = d_out_err; a.out_iters = d_out_iters;
   a.out_corr = d_out_corr;
   a.epsilon = epsilon; a.stopping_thresh = stopping_thresh; a.max_iters = max_iters; a.flags = flags;
+  bool prune = (flags & kFlagPrune) != 0;
+  if (const char* e = getenv("LSLAM_ICP_PRUNE")) prune = atoi(e) != 0;
+  if (prune && icp_pruned_supported(dim, max_src_n, max_tgt_n)) {
+    // sorted copies: S x max points is an upper bound of the packed sizes (the offsets live on the device)
+    static thread_local PruneScratch sc{};
+    static thread_local size_t cap_src = 0, cap_tgt = 0;
+    static thread_local int sc_dev = -1;
+    int dev = 0;
+    LSLAM_HIP_TRY(hipGetDevice(&dev));
+    const size_t need_src = ((size_t)S + 1) * (size_t)max_src_n, need_tgt = ((size_t)S + 1) * (size_t)max_tgt_n;   // +1: a scan sequence shifts one of the offset arrays by a scan
+    if (dev != sc_dev || need_src > cap_src || need_tgt > cap_tgt) {
+      LSLAM_HIP_TRY(hipDeviceSynchronize());                 // earlier launches may still read the old buffers
+      if (sc.src_sorted) (void)hipFree(sc.src_sorted);
+      if (sc.src_index) (void)hipFree(sc.src_index);
+      if (sc.tgt_sorted) (void)hipFree(sc.tgt_sorted);
+      if (sc.tgt_index) (void)hipFree(sc.tgt_index);
+      sc = PruneScratch{}; cap_src = cap_tgt = 0; sc_dev = dev;
+      LSLAM_HIP_TRY(hipMalloc(&sc.src_sorted, sizeof(float2) * need_src));
+      LSLAM_HIP_TRY(hipMalloc(&sc.src_index, sizeof(uint16_t) * need_src));
+      LSLAM_HIP_TRY(hipMalloc(&sc.tgt_sorted, sizeof(float2) * need_tgt));
+      LSLAM_HIP_TRY(hipMalloc(&sc.tgt_index, sizeof(uint16_t) * need_tgt));
+      cap_src = need_src; cap_tgt = need_tgt;
+    }
+    LSLAM_HIP_TRY(launch_icp_pruned(a, sc, S, max_src_n, max_tgt_n, static_cast<hipStream_t>(stream)));
+    return LSLAM_OK;
+  }
   LSLAM_HIP_TRY(launch_icp_batch(a, dim, S, max_src_n, max_tgt_n, tuning_from_env(), static_cast<hipStream_t>(stream)));
   return LSLAM_OK;
 }

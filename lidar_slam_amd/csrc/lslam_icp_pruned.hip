@@ -1,0 +1,387 @@
+// lslam_icp_pruned.hip — the batched planar ICP with EXACT chunk pruning (opt-in: LSLAM_ICP_PRUNE).
+//
+// Same operator, same results as icp_batch_kernel (modules/icp.py:123-189): every source point still
+// gets its exact float32 nearest target, lowest original index on ties.  What changes is how many
+// pair evaluations that takes.  Both clouds of a problem are first put into Morton order of a uniform
+// grid over the target's bounding box (icp_sort_kernel: bitonic sort of (cell, index) keys in LDS,
+// once per problem).  Then
+//   * 16 consecutive sorted targets (a chunk) are spatially compact: their bounding box is kept in LDS;
+//   * the 64·P consecutive sorted sources of a wave are spatially compact too: each iteration the
+//     wave reduces the bounding box of its transformed points;
+//   * a chunk whose box is farther from the wave's box than every lane's current best distance cannot
+//     contain a nearer (or equally near) point for any lane: it is skipped with one wave-uniform
+//     branch.  The best distance starts from the previous iteration's match, so from the second
+//     iteration on almost everything is skipped at once.
+// The bound is made conservative against float32 rounding (factor 1 − 1e-5) and the comparison is
+// strict, so a skipped chunk can never hold the argmin or a tie.  Equal distances in two evaluated
+// chunks (duplicate points) are resolved by a rare exhaustive pass ordered by original index.
+#include <hip/hip_runtime.h>
+
+#include "lslam_device.h"
+#include "lslam_kernels.h"
+
+namespace lslam {
+
+constexpr int kPruneChunk = 16;
+constexpr int kSortThreads = 256;
+constexpr float kPruneSafety = 0.99999f;
+
+__device__ __forceinline__ unsigned morton5(unsigned x, unsigned y) {      // interleave two 5-bit coordinates
+  unsigned r = 0;
+#pragma unroll
+  for (int b = 0; b < 5; ++b) r |= ((x >> b) & 1u) << (2 * b) | ((y >> b) & 1u) << (2 * b + 1);
+  return r;
+}
+
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ascending bitonic sort of `len` (power of two) uint32 keys in LDS
+__device__ inline void bitonic_sort(unsigned* keys, int len) {
+  for (int k = 2; k <= len; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned a = keys[i], b = keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+    }
+  __syncthreads();
+}
+
+// One workgroup per problem: Morton-sorted copies of target and source + their original indices.
+__global__ void __launch_bounds__(kSortThreads)
+icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned* keys = reinterpret_cast<unsigned*>(smem);
+  __shared__ float sbox[4];
+  __shared__ float red[kSortThreads / 64][4];
+  const int pair = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int64_t s0 = a.src_off[pair], t0 = a.tgt_off[pair];
+  const int n = (int)(a.src_off[pair + 1] - s0), m = (int)(a.tgt_off[pair + 1] - t0);
+  const float2* src = reinterpret_cast<const float2*>(a.src) + s0;
+  const float2* tgt = reinterpret_cast<const float2*>(a.tgt) + t0;
+
+  // bounding box of the target
+  float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+  for (int j = tid; j < m; j += kSortThreads) {
+    const float2 q = tgt[j];
+    x0 = fminf(x0, q.x); y0 = fminf(y0, q.y); x1 = fmaxf(x1, q.x); y1 = fmaxf(y1, q.y);
+  }
+  x0 = wave_min_f(x0); y0 = wave_min_f(y0); x1 = wave_max_f(x1); y1 = wave_max_f(y1);
+  if ((tid & 63) == 0) { red[tid >> 6][0] = x0; red[tid >> 6][1] = y0; red[tid >> 6][2] = x1; red[tid >> 6][3] = y1; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < kSortThreads / 64; ++w) {
+      x0 = fminf(x0, red[w][0]); y0 = fminf(y0, red[w][1]); x1 = fmaxf(x1, red[w][2]); y1 = fmaxf(y1, red[w][3]);
+    }
+    sbox[0] = x0; sbox[1] = y0; sbox[2] = x1; sbox[3] = y1;
+  }
+  __syncthreads();
+  x0 = sbox[0]; y0 = sbox[1]; x1 = sbox[2]; y1 = sbox[3];
+  const int G = m >= 2048 ? 32 : (m >= 512 ? 16 : 8);
+  const float sx = (x1 > x0) ? (float)G / (x1 - x0) : 0.f, sy = (y1 > y0) ? (float)G / (y1 - y0) : 0.f;
+  auto cell_of = [&](float x, float y) -> unsigned {
+    int gx = (int)((x - x0) * sx), gy = (int)((y - y0) * sy);
+    gx = min(max(gx, 0), G - 1); gy = min(max(gy, 0), G - 1);
+    return morton5((unsigned)gx, (unsigned)gy);
+  };
+
+  // ---- target ----
+  for (int j = tid; j < len_pow2; j += kSortThreads) {
+    unsigned k = 0xffffffffu;
+    if (j < m) { const float2 q = tgt[j]; k = (cell_of(q.x, q.y) << 13) | (unsigned)j; }
+    keys[j] = k;
+  }
+  bitonic_sort(keys, len_pow2);
+  for (int j = tid; j < m; j += kSortThreads) {
+    const unsigned o = keys[j] & 8191u;
+    sc.tgt_sorted[t0 + j] = tgt[o];
+    sc.tgt_index[t0 + j] = (uint16_t)o;
+  }
+  __syncthreads();
+  // ---- source, placed by its initial transform into the target's grid ----
+  const double* T = a.init_T + (int64_t)16 * pair;
+  const float t00 = (float)T[0], t01 = (float)T[1], t03 = (float)T[3], t10 = (float)T[4], t11 = (float)T[5], t13 = (float)T[7];
+  for (int i = tid; i < len_pow2; i += kSortThreads) {
+    unsigned k = 0xffffffffu;
+    if (i < n) {
+      const float2 p = src[i];
+      k = (cell_of(t00 * p.x + t01 * p.y + t03, t10 * p.x + t11 * p.y + t13) << 13) | (unsigned)i;
+    }
+    keys[i] = k;
+  }
+  bitonic_sort(keys, len_pow2);
+  for (int i = tid; i < n; i += kSortThreads) {
+    const unsigned o = keys[i] & 8191u;
+    sc.src_sorted[s0 + i] = src[o];
+    sc.src_index[s0 + i] = (uint16_t)o;
+  }
+}
+
+template <int P>
+__global__ void __launch_bounds__(kIcpBatchMaxThreads)
+icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
+  constexpr int CHUNK = kPruneChunk;
+  constexpr int kAcc = AccLayout<2>::kTotal;
+  extern __shared__ __align__(16) unsigned char smem[];
+  float2* tile = reinterpret_cast<float2*>(smem);                                   // sorted targets, padded
+  float4* aabb = reinterpret_cast<float4*>(smem + lay.aabb_off);                    // per chunk {x0,y0,x1,y1}
+  uint16_t* tidx = reinterpret_cast<uint16_t*>(smem + lay.tidx_off);                // original target index
+  float2* sh_src = reinterpret_cast<float2*>(smem + lay.src_off);                   // sorted sources
+  double* sh_red = reinterpret_cast<double*>(smem + lay.red_off);                   // [waves][kAcc]
+  double* sh_T = sh_red + (size_t)kIcpBatchMaxWaves * kAcc;
+  int* sh_flag = reinterpret_cast<int*>(sh_T + 16);
+
+  const int pair = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int64_t s0 = args.src_off[pair], t0 = args.tgt_off[pair];
+  const int n = (int)(args.src_off[pair + 1] - s0), m = (int)(args.tgt_off[pair + 1] - t0);
+  const bool box = (args.flags & kFlagNormalize) != 0;
+  const int nchunks = (m + CHUNK - 1) / CHUNK;
+
+  if (tid < 16) sh_T[tid] = args.init_T[(int64_t)16 * pair + tid];
+  for (int j = tid; j < nchunks * CHUNK; j += blockDim.x) {
+    tile[j] = (j < m) ? sc.tgt_sorted[t0 + j] : make_float2(kFar, kFar);
+    tidx[j] = (j < m) ? sc.tgt_index[t0 + j] : (uint16_t)0xffff;
+  }
+  for (int i = tid; i < n; i += blockDim.x) sh_src[i] = sc.src_sorted[s0 + i];
+  __syncthreads();
+  for (int c = tid; c < nchunks; c += blockDim.x) {        // boxes over the real points only
+    float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+    for (int k = 0; k < CHUNK && c * CHUNK + k < m; ++k) {
+      const float2 q = tile[c * CHUNK + k];
+      x0 = fminf(x0, q.x); y0 = fminf(y0, q.y); x1 = fmaxf(x1, q.x); y1 = fmaxf(y1, q.y);
+    }
+    aabb[c] = make_float4(x0, y0, x1, y1);
+  }
+  __syncthreads();
+
+  StopState st;
+  stop_init(st);
+  double err_out = 0.0;
+  int prev[P];                                            // sorted position matched in the previous iteration
+#pragma unroll
+  for (int p = 0; p < P; ++p) prev[p] = -1;
+  const bool wave_live = (tid & ~63) * P < n;
+
+  for (;;) {
+    double T[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) T[r][c] = wave_uniform(sh_T[4 * r + c]);
+
+    PairAcc<2> acc;
+    acc.clear();
+    if (wave_live) {
+      float ax[P], ay[P];
+      float wx0 = INFINITY, wy0 = INFINITY, wx1 = -INFINITY, wy1 = -INFINITY;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = tid * P + p;
+        ax[p] = 0.f; ay[p] = 0.f;
+        if (i < n) {
+          const float2 v = sh_src[i];
+          ax[p] = (float)(T[0][0] * (double)v.x + T[0][1] * (double)v.y + T[0][3]);      // icp.py:116
+          ay[p] = (float)(T[1][0] * (double)v.x + T[1][1] * (double)v.y + T[1][3]);
+          wx0 = fminf(wx0, ax[p]); wy0 = fminf(wy0, ay[p]); wx1 = fmaxf(wx1, ax[p]); wy1 = fmaxf(wy1, ay[p]);
+        }
+      }
+      wx0 = wave_min_f(wx0); wy0 = wave_min_f(wy0); wx1 = wave_max_f(wx1); wy1 = wave_max_f(wy1);
+
+      // ---- start from last iteration's match: a tight bound before the first chunk ------------
+      float best[P];
+      int bchunk[P];
+      bool tie = false;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = tid * P + p;
+        best[p] = (i < n) ? INFINITY : -INFINITY;          // lanes without a point never ask for a chunk
+        bchunk[p] = 0;
+        if (i < n && prev[p] >= 0) {
+          const float2 q = tile[prev[p]];
+          best[p] = dist2(ax[p], ay[p], q.x, q.y);
+          bchunk[p] = prev[p] / CHUNK;
+        }
+      }
+
+      // ---- sweep with wave-uniform skipping ----------------------------------------------------
+      const float4* t4 = reinterpret_cast<const float4*>(tile);
+      for (int c = 0; c < nchunks; ++c) {
+        const float4 b = aabb[c];
+        const float dx = fmaxf(fmaxf(b.x - wx1, wx0 - b.z), 0.f);
+        const float dy = fmaxf(fmaxf(b.y - wy1, wy0 - b.w), 0.f);
+        const float lb = __builtin_fmaf(dy, dy, dx * dx) * kPruneSafety;
+        bool need = false;
+#pragma unroll
+        for (int p = 0; p < P; ++p) need |= best[p] >= lb;
+        if (!__any(need)) continue;                        // nothing in this chunk can beat or tie any lane
+        float4 v[CHUNK / 2];
+#pragma unroll
+        for (int k = 0; k < CHUNK / 2; ++k) v[k] = t4[c * (CHUNK / 2) + k];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          float mn = dist2(ax[p], ay[p], v[0].x, v[0].y);
+          mn = fminf(mn, dist2(ax[p], ay[p], v[0].z, v[0].w));
+#pragma unroll
+          for (int k = 1; k < CHUNK / 2; ++k) {
+            const float d0 = dist2(ax[p], ay[p], v[k].x, v[k].y);
+            const float d1 = dist2(ax[p], ay[p], v[k].z, v[k].w);
+            mn = fminf(fminf(d0, d1), mn);
+          }
+          tie |= (mn == best[p]) && (c != bchunk[p]) && (mn < INFINITY);
+          const bool lt = mn < best[p];
+          bchunk[p] = lt ? c : bchunk[p];
+          best[p] = lt ? mn : best[p];
+        }
+      }
+
+      // ---- fix-up inside the winning chunk: (distance, original index) lexicographic ------------
+      int pos[P], oidx[P];
+      float bd[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int j0 = bchunk[p] * CHUNK;
+        bd[p] = INFINITY; pos[p] = j0; oidx[p] = 0x7fffffff;
+#pragma unroll
+        for (int kk = 0; kk < CHUNK; ++kk) {
+          const int k = (kk + lane) & (CHUNK - 1);
+          const float2 q = tile[j0 + k];
+          const int o = tidx[j0 + k];
+          const float d = dist2(ax[p], ay[p], q.x, q.y);
+          if (d < bd[p] || (d == bd[p] && o < oidx[p])) { bd[p] = d; pos[p] = j0 + k; oidx[p] = o; }
+        }
+      }
+      // ---- equal minima in different chunks (duplicate points): exhaustive pass by original index --
+      if (__any(tie)) {
+        for (int j = 0; j < m; ++j) {
+          const float2 q = tile[j];
+          const int o = tidx[j];
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            const float d = dist2(ax[p], ay[p], q.x, q.y);
+            if (d < bd[p] || (d == bd[p] && o < oidx[p])) { bd[p] = d; pos[p] = j; oidx[p] = o; }
+          }
+        }
+      }
+
+      // ---- moments in float64 ------------------------------------------------------------------
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = tid * P + p;
+        prev[p] = pos[p];
+        if (i < n) {
+          const float2 v = sh_src[i];
+          const float2 q = tile[pos[p]];
+          double pd[2], qd[2];
+          pd[0] = T[0][0] * (double)v.x + T[0][1] * (double)v.y + T[0][3];
+          pd[1] = T[1][0] * (double)v.x + T[1][1] * (double)v.y + T[1][3];
+          qd[0] = (double)q.x; qd[1] = (double)q.y;
+          acc.add(pd, qd, box);
+          if (args.out_corr) args.out_corr[s0 + sc.src_index[s0 + i]] = oidx[p];
+        }
+      }
+    }
+
+    acc.wave_reduce(box);
+    if (lane == 0) acc.store(sh_red + (size_t)wave * kAcc);
+    __syncthreads();
+    if (wave == 0) {
+      constexpr int kS = AccLayout<2>::kSums;
+      double col = 0.0;
+      if (lane < kAcc) {
+        col = sh_red[lane];
+        for (int w = 1; w < nwaves; ++w) {
+          const double v = sh_red[(size_t)w * kAcc + lane];
+          col = (lane < kS) ? col + v : ((lane < kS + 2) ? fmin(col, v) : fmax(col, v));
+        }
+      }
+      double tot[kAcc];
+#pragma unroll
+      for (int k = 0; k < kAcc; ++k) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(col), k);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(col), k);
+        tot[k] = __hiloint2double(hi, lo);
+      }
+      Moments mo;
+      combine_partials<2>(tot, 1, kAcc, box, mo);
+      double Tstep[16], Tprev[16], Tnew[16];
+      step_from_moments(mo, true, Tstep);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Tprev[i] = sh_T[i];
+      matmul4(Tstep, Tprev, Tnew);
+      err_out = error_from_moments(mo, box);
+      const bool stop = stop_after_iteration(st, err_out, args.epsilon, args.stopping_thresh, args.max_iters);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sh_T[i] = Tnew[i];
+        sh_flag[0] = stop ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    if (sh_flag[0]) break;
+  }
+
+  if (tid < 16) args.out_T[(int64_t)16 * pair + tid] = sh_T[tid];
+  if (tid == 0) {
+    args.out_err[pair] = err_out;
+    args.out_iters[pair] = st.executed;
+  }
+}
+
+// ---- launch ------------------------------------------------------------------------------------------
+bool icp_pruned_supported(int dim, int64_t max_src_n, int64_t max_tgt_n) {
+  return dim == 2 && max_src_n >= 1 && max_src_n <= kPruneMaxPoints && max_tgt_n <= kPruneMaxPoints;
+}
+
+hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n,
+                             hipStream_t stream) {
+  // 1. sort
+  int len = 64;
+  while (len < max_src_n || len < max_tgt_n) len <<= 1;
+  hipLaunchKernelGGL(icp_sort_kernel, dim3(S), dim3(kSortThreads), sizeof(unsigned) * (size_t)len, stream, a, sc, len);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // 2. iterate
+  const int P = max_src_n <= 2048 ? 2 : 4;
+  int threads = (int)((((max_src_n + P - 1) / P + 63) / 64) * 64);
+  if (threads < 64) threads = 64;
+  const int padded = (int)(((max_tgt_n + kPruneChunk - 1) / kPruneChunk) * kPruneChunk);
+  PruneLayout lay{};
+  size_t off = (size_t)padded * sizeof(float2);
+  lay.aabb_off = (uint32_t)off; off += (size_t)(padded / kPruneChunk) * sizeof(float4);
+  lay.tidx_off = (uint32_t)off; off += (((size_t)padded * sizeof(uint16_t)) + 15) & ~(size_t)15;
+  lay.src_off = (uint32_t)off; off += (((size_t)max_src_n * sizeof(float2)) + 15) & ~(size_t)15;
+  lay.red_off = (uint32_t)off;
+  const size_t smem = off + sizeof(double) * ((size_t)kIcpBatchMaxWaves * AccLayout<2>::kTotal + 16) + 16;
+  if (P == 2) {
+    if (smem > 48 * 1024) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(icp_pruned_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(icp_pruned_kernel<2>, dim3(S), dim3(threads), smem, stream, a, sc, lay);
+  } else {
+    if (smem > 48 * 1024) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(icp_pruned_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(icp_pruned_kernel<4>, dim3(S), dim3(threads), smem, stream, a, sc, lay);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace lslam

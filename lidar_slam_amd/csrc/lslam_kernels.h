@@ -52,6 +52,18 @@ struct IcpBatchTuning {
   int src_in_lds = 0;        // 0 = automatic, 1 = always, 2 = never
 };
 
+// ---- exact chunk pruning (lslam_icp_pruned.hip) ----------------------------------------------------
+constexpr uint32_t kFlagPrune = 2u;        // == LSLAM_ICP_PRUNE
+constexpr int kPruneMaxPoints = 4096;      // per cloud: both sorted clouds + boxes + indices must fit LDS
+struct PruneScratch {                      // Morton-sorted copies, laid out like the original offsets
+  float2* src_sorted; uint16_t* src_index;
+  float2* tgt_sorted; uint16_t* tgt_index;
+};
+struct PruneLayout { uint32_t aabb_off, tidx_off, src_off, red_off; };
+bool icp_pruned_supported(int dim, int64_t max_src_n, int64_t max_tgt_n);
+hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n,
+                             hipStream_t stream);
+
 hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, int64_t max_tgt_n,
                             const IcpBatchTuning& tune, hipStream_t stream);
 
