@@ -209,6 +209,18 @@ def main():
                          "hbm_compulsory_bytes_per_launch": 2 * S * P * 8 + S * 2 * 128,
                          "note": "fp32 VALU-issue bound (all-pairs NN out of LDS); HBM sees only the compulsory bytes. peak = fp32 vector peak"},
         }
+        if rank == 0 and world == 1:
+            # the same batch with exact chunk pruning (opt-in LSLAM_ICP_PRUNE flag; identical correspondences)
+            oT2 = torch.empty_like(out_T)
+            def step_pruned():
+                B.icp_batch_dev(src.data_ptr(), off.data_ptr(), tgt.data_ptr(), off.data_ptr(), 2, init.data_ptr(), S, P, P,
+                                oT2.data_ptr(), out_err.data_ptr(), out_it.data_ptr(), None, epsilon=0.0,
+                                max_iters=I - 1, stopping_thresh=0.0, stream=stream, prune=True)
+            ms_p = _time(torch, step_pruned, 2, a.steps)
+            result["pruned"] = {"what": "same workload with LSLAM_ICP_PRUNE: Morton-sorted clouds, wave-uniform box tests, exact results",
+                                "ms_per_step": ms_p, "icp_iterations_per_sec": S * I / (ms_p * 1e-3),
+                                "speedup_vs_all_pairs_sweep": (dt / a.steps * 1e3) / ms_p,
+                                "max_abs_T_difference": float((oT2 - out_T).abs().max().item())}
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             n = min(a.cpu_sample_pairs, S)
             h_src, h_tgt, h_init = src[: n * P].cpu().numpy().astype(np.float64), tgt[: n * P].cpu().numpy().astype(np.float64), init[:n].cpu().numpy()

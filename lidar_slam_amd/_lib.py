@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "liblslam_hip.so")
 
 OK, ERR_BAD_ARG, ERR_EMPTY_TARGET, ERR_NONFINITE, ERR_HIP = 0, -1, -2, -3, -4
 ICP_NORMALIZE_ERROR = 1
+ICP_PRUNE = 2
 PRE_POLAR, PRE_DBSCAN, PRE_RADIAL = 1, 2, 4
 
 

@@ -23,6 +23,7 @@
 namespace lslam {
 
 constexpr int kPruneChunk = 16;
+constexpr int kPruneSuper = 8;
 constexpr int kSortThreads = 256;
 constexpr float kPruneSafety = 0.99999f;
 
@@ -133,15 +134,17 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2) {
 }
 
 template <int P>
-__global__ void __launch_bounds__(kIcpBatchMaxThreads)
+__global__ void __launch_bounds__(kIcpBatchMaxThreads, 8)      // ≤ 64 VGPRs: two 16-wave workgroups per CU (measured 1.3× faster than 119 VGPRs / one workgroup)
 icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   constexpr int CHUNK = kPruneChunk;
+  constexpr int SUPER = kPruneSuper;                            // chunks per super-chunk (second-level box)
   constexpr int kAcc = AccLayout<2>::kTotal;
   extern __shared__ __align__(16) unsigned char smem[];
   float2* tile = reinterpret_cast<float2*>(smem);                                   // sorted targets, padded
   float4* aabb = reinterpret_cast<float4*>(smem + lay.aabb_off);                    // per chunk {x0,y0,x1,y1}
+  float4* aabb2 = reinterpret_cast<float4*>(smem + lay.aabb2_off);                  // per super-chunk
   uint16_t* tidx = reinterpret_cast<uint16_t*>(smem + lay.tidx_off);                // original target index
-  float2* sh_src = reinterpret_cast<float2*>(smem + lay.src_off);                   // sorted sources
+  uint16_t* sh_prev = reinterpret_cast<uint16_t*>(smem + lay.prev_off);             // last match of every source
   double* sh_red = reinterpret_cast<double*>(smem + lay.red_off);                   // [waves][kAcc]
   double* sh_T = sh_red + (size_t)kIcpBatchMaxWaves * kAcc;
   int* sh_flag = reinterpret_cast<int*>(sh_T + 16);
@@ -150,15 +153,17 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int64_t s0 = args.src_off[pair], t0 = args.tgt_off[pair];
   const int n = (int)(args.src_off[pair + 1] - s0), m = (int)(args.tgt_off[pair + 1] - t0);
+  const float2* __restrict__ ssrc = sc.src_sorted + s0;        // Morton-sorted sources (L2-resident)
   const bool box = (args.flags & kFlagNormalize) != 0;
   const int nchunks = (m + CHUNK - 1) / CHUNK;
+  const int nsuper = (nchunks + SUPER - 1) / SUPER;
 
   if (tid < 16) sh_T[tid] = args.init_T[(int64_t)16 * pair + tid];
   for (int j = tid; j < nchunks * CHUNK; j += blockDim.x) {
     tile[j] = (j < m) ? sc.tgt_sorted[t0 + j] : make_float2(kFar, kFar);
     tidx[j] = (j < m) ? sc.tgt_index[t0 + j] : (uint16_t)0xffff;
   }
-  for (int i = tid; i < n; i += blockDim.x) sh_src[i] = sc.src_sorted[s0 + i];
+  for (int i = tid; i < n; i += blockDim.x) sh_prev[i] = 0xffff;
   __syncthreads();
   for (int c = tid; c < nchunks; c += blockDim.x) {        // boxes over the real points only
     float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
@@ -169,14 +174,21 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
     aabb[c] = make_float4(x0, y0, x1, y1);
   }
   __syncthreads();
+  for (int u = tid; u < nsuper; u += blockDim.x) {
+    float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+    for (int k = 0; k < SUPER && u * SUPER + k < nchunks; ++k) {
+      const float4 b = aabb[u * SUPER + k];
+      x0 = fminf(x0, b.x); y0 = fminf(y0, b.y); x1 = fmaxf(x1, b.z); y1 = fmaxf(y1, b.w);
+    }
+    aabb2[u] = make_float4(x0, y0, x1, y1);
+  }
+  __syncthreads();
 
   StopState st;
   stop_init(st);
   double err_out = 0.0;
-  int prev[P];                                            // sorted position matched in the previous iteration
-#pragma unroll
-  for (int p = 0; p < P; ++p) prev[p] = -1;
-  const bool wave_live = (tid & ~63) * P < n;
+  const int per_pass = blockDim.x * P;
+  const int passes = n > 0 ? (n + per_pass - 1) / per_pass : 1;
 
   for (;;) {
     double T[2][4];
@@ -185,17 +197,18 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) T[r][c] = wave_uniform(sh_T[4 * r + c]);
 
-    PairAcc<2> acc;
-    acc.clear();
-    if (wave_live) {
+    // ---- phase A: nearest neighbours (float32); the matches go to LDS (they also seed the next iteration)
+    for (int pass = 0; pass < passes; ++pass) {
+      const int base = pass * per_pass;
+      if (base + (tid & ~63) * P >= n) continue;           // this wave owns no source in this pass
       float ax[P], ay[P];
       float wx0 = INFINITY, wy0 = INFINITY, wx1 = -INFINITY, wy1 = -INFINITY;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        const int i = tid * P + p;
+        const int i = base + tid * P + p;
         ax[p] = 0.f; ay[p] = 0.f;
         if (i < n) {
-          const float2 v = sh_src[i];
+          const float2 v = ssrc[i];
           ax[p] = (float)(T[0][0] * (double)v.x + T[0][1] * (double)v.y + T[0][3]);      // icp.py:116
           ay[p] = (float)(T[1][0] * (double)v.x + T[1][1] * (double)v.y + T[1][3]);
           wx0 = fminf(wx0, ax[p]); wy0 = fminf(wy0, ay[p]); wx1 = fmaxf(wx1, ax[p]); wy1 = fmaxf(wy1, ay[p]);
@@ -209,44 +222,60 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
       bool tie = false;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        const int i = tid * P + p;
+        const int i = base + tid * P + p;
         best[p] = (i < n) ? INFINITY : -INFINITY;          // lanes without a point never ask for a chunk
         bchunk[p] = 0;
-        if (i < n && prev[p] >= 0) {
-          const float2 q = tile[prev[p]];
-          best[p] = dist2(ax[p], ay[p], q.x, q.y);
-          bchunk[p] = prev[p] / CHUNK;
+        if (i < n) {
+          const int pv = sh_prev[i];
+          if (pv != 0xffff) {
+            const float2 q = tile[pv];
+            best[p] = dist2(ax[p], ay[p], q.x, q.y);
+            bchunk[p] = pv / CHUNK;
+          }
         }
       }
 
-      // ---- sweep with wave-uniform skipping ----------------------------------------------------
+      // ---- sweep with two levels of wave-uniform skipping ---------------------------------------
       const float4* t4 = reinterpret_cast<const float4*>(tile);
-      for (int c = 0; c < nchunks; ++c) {
-        const float4 b = aabb[c];
-        const float dx = fmaxf(fmaxf(b.x - wx1, wx0 - b.z), 0.f);
-        const float dy = fmaxf(fmaxf(b.y - wy1, wy0 - b.w), 0.f);
-        const float lb = __builtin_fmaf(dy, dy, dx * dx) * kPruneSafety;
-        bool need = false;
+      for (int u = 0; u < nsuper; ++u) {
+        {
+          const float4 b = aabb2[u];
+          const float dx = fmaxf(fmaxf(b.x - wx1, wx0 - b.z), 0.f);
+          const float dy = fmaxf(fmaxf(b.y - wy1, wy0 - b.w), 0.f);
+          const float lb = __builtin_fmaf(dy, dy, dx * dx) * kPruneSafety;
+          bool need = false;
 #pragma unroll
-        for (int p = 0; p < P; ++p) need |= best[p] >= lb;
-        if (!__any(need)) continue;                        // nothing in this chunk can beat or tie any lane
-        float4 v[CHUNK / 2];
+          for (int p = 0; p < P; ++p) need |= best[p] >= lb;
+          if (!__any(need)) continue;                      // none of these 128 targets matters to this wave
+        }
+        const int c_end = min(nchunks, (u + 1) * SUPER);
+        for (int c = u * SUPER; c < c_end; ++c) {
+          const float4 b = aabb[c];
+          const float dx = fmaxf(fmaxf(b.x - wx1, wx0 - b.z), 0.f);
+          const float dy = fmaxf(fmaxf(b.y - wy1, wy0 - b.w), 0.f);
+          const float lb = __builtin_fmaf(dy, dy, dx * dx) * kPruneSafety;
+          bool need = false;
 #pragma unroll
-        for (int k = 0; k < CHUNK / 2; ++k) v[k] = t4[c * (CHUNK / 2) + k];
+          for (int p = 0; p < P; ++p) need |= best[p] >= lb;
+          if (!__any(need)) continue;                      // nothing in this chunk can beat or tie any lane
+          float4 v[CHUNK / 2];
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-          float mn = dist2(ax[p], ay[p], v[0].x, v[0].y);
-          mn = fminf(mn, dist2(ax[p], ay[p], v[0].z, v[0].w));
+          for (int k = 0; k < CHUNK / 2; ++k) v[k] = t4[c * (CHUNK / 2) + k];
 #pragma unroll
-          for (int k = 1; k < CHUNK / 2; ++k) {
-            const float d0 = dist2(ax[p], ay[p], v[k].x, v[k].y);
-            const float d1 = dist2(ax[p], ay[p], v[k].z, v[k].w);
-            mn = fminf(fminf(d0, d1), mn);
+          for (int p = 0; p < P; ++p) {
+            float mn = dist2(ax[p], ay[p], v[0].x, v[0].y);
+            mn = fminf(mn, dist2(ax[p], ay[p], v[0].z, v[0].w));
+#pragma unroll
+            for (int k = 1; k < CHUNK / 2; ++k) {
+              const float d0 = dist2(ax[p], ay[p], v[k].x, v[k].y);
+              const float d1 = dist2(ax[p], ay[p], v[k].z, v[k].w);
+              mn = fminf(fminf(d0, d1), mn);
+            }
+            tie |= (mn == best[p]) && (c != bchunk[p]) && (mn < INFINITY);
+            const bool lt = mn < best[p];
+            bchunk[p] = lt ? c : bchunk[p];
+            best[p] = lt ? mn : best[p];
           }
-          tie |= (mn == best[p]) && (c != bchunk[p]) && (mn < INFINITY);
-          const bool lt = mn < best[p];
-          bchunk[p] = lt ? c : bchunk[p];
-          best[p] = lt ? mn : best[p];
         }
       }
 
@@ -279,20 +308,32 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
         }
       }
 
-      // ---- moments in float64 ------------------------------------------------------------------
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        const int i = tid * P + p;
-        prev[p] = pos[p];
+        const int i = base + tid * P + p;
+        if (i < n) sh_prev[i] = (uint16_t)pos[p];
+      }
+    }
+
+    // ---- phase B: float64 moments of the matched pairs (kept apart from the sweep: the 28 accumulator
+    // registers are not live while the search runs) ------------------------------------------------
+    PairAcc<2> acc;
+    acc.clear();
+    for (int pass = 0; pass < passes; ++pass) {
+      const int base = pass * per_pass;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = base + tid * P + p;
         if (i < n) {
-          const float2 v = sh_src[i];
-          const float2 q = tile[pos[p]];
+          const int ps = sh_prev[i];
+          const float2 v = ssrc[i];
+          const float2 q = tile[ps];
           double pd[2], qd[2];
           pd[0] = T[0][0] * (double)v.x + T[0][1] * (double)v.y + T[0][3];
           pd[1] = T[1][0] * (double)v.x + T[1][1] * (double)v.y + T[1][3];
           qd[0] = (double)q.x; qd[1] = (double)q.y;
           acc.add(pd, qd, box);
-          if (args.out_corr) args.out_corr[s0 + sc.src_index[s0 + i]] = oidx[p];
+          if (args.out_corr) args.out_corr[s0 + sc.src_index[s0 + i]] = tidx[ps];
         }
       }
     }
@@ -357,31 +398,34 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // 2. iterate
-  const int P = max_src_n <= 2048 ? 2 : 4;
+  int P = 2;
+  if (const char* env = getenv("LSLAM_ICP_PRUNE_P")) P = atoi(env);
+  if (P != 1 && P != 2 && P != 4) P = 2;
   int threads = (int)((((max_src_n + P - 1) / P + 63) / 64) * 64);
   if (threads < 64) threads = 64;
+  if (threads > kIcpBatchMaxThreads) threads = kIcpBatchMaxThreads;      // more sources: several passes
   const int padded = (int)(((max_tgt_n + kPruneChunk - 1) / kPruneChunk) * kPruneChunk);
+  const int nchunks = padded / kPruneChunk, nsuper = (nchunks + kPruneSuper - 1) / kPruneSuper;
   PruneLayout lay{};
+  auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
   size_t off = (size_t)padded * sizeof(float2);
-  lay.aabb_off = (uint32_t)off; off += (size_t)(padded / kPruneChunk) * sizeof(float4);
-  lay.tidx_off = (uint32_t)off; off += (((size_t)padded * sizeof(uint16_t)) + 15) & ~(size_t)15;
-  lay.src_off = (uint32_t)off; off += (((size_t)max_src_n * sizeof(float2)) + 15) & ~(size_t)15;
+  lay.aabb_off = (uint32_t)off; off += (size_t)nchunks * sizeof(float4);
+  lay.aabb2_off = (uint32_t)off; off += (size_t)nsuper * sizeof(float4);
+  lay.tidx_off = (uint32_t)off; off += up((size_t)padded * sizeof(uint16_t));
+  lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));
   lay.red_off = (uint32_t)off;
   const size_t smem = off + sizeof(double) * ((size_t)kIcpBatchMaxWaves * AccLayout<2>::kTotal + 16) + 16;
-  if (P == 2) {
+  auto launch = [&](auto kernel) -> hipError_t {
     if (smem > 48 * 1024) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(icp_pruned_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (e != hipSuccess) return e;
+      hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (ee != hipSuccess) return ee;
     }
-    hipLaunchKernelGGL(icp_pruned_kernel<2>, dim3(S), dim3(threads), smem, stream, a, sc, lay);
-  } else {
-    if (smem > 48 * 1024) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(icp_pruned_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(icp_pruned_kernel<4>, dim3(S), dim3(threads), smem, stream, a, sc, lay);
-  }
-  return hipGetLastError();
+    hipLaunchKernelGGL(kernel, dim3(S), dim3(threads), smem, stream, a, sc, lay);
+    return hipGetLastError();
+  };
+  if (P == 1) return launch(icp_pruned_kernel<1>);
+  if (P == 2) return launch(icp_pruned_kernel<2>);
+  return launch(icp_pruned_kernel<4>);
 }
 
 }  // namespace lslam

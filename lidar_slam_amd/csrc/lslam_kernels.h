@@ -59,7 +59,7 @@ struct PruneScratch {                      // Morton-sorted copies, laid out lik
   float2* src_sorted; uint16_t* src_index;
   float2* tgt_sorted; uint16_t* tgt_index;
 };
-struct PruneLayout { uint32_t aabb_off, tidx_off, src_off, red_off; };
+struct PruneLayout { uint32_t aabb_off, aabb2_off, tidx_off, prev_off, red_off; };
 bool icp_pruned_supported(int dim, int64_t max_src_n, int64_t max_tgt_n);
 hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n,
                              hipStream_t stream);

@@ -323,3 +323,49 @@ def test_loop_closure_batch_matches_per_pair_reference_semantics(icp, tmp_path):
         assert ok[list(pairs[:, 0]).index(i)] == (np.linalg.norm(T[:2, 2]) < 0.25 and ang < 2.0)
     paths = save_scan_matching_outputs(g["poses"], g["relative_poses"], 20, out_dir=str(tmp_path))
     assert np.load(paths[0]).shape == (32, 3) and np.load(paths[1]).shape == (31, 3, 3)
+
+
+def test_exact_pruning_gives_the_brute_force_answers(icp):
+    """LSLAM_ICP_PRUNE: Morton-sorted clouds + box tests must not change a single correspondence or
+    iteration count (duplicates, ragged sizes, several passes per problem, normalised error)"""
+    from lidar_slam_amd.batch import icp_batch, pack_clouds
+    from lidar_slam_amd.synth import batch_c4
+    g = golden("icp_planar.npz")
+    srcs, flat, off, tgt, toff, init = batch_of(g)
+    a = icp_batch(flat, off, tgt, toff, init, epsilon=0.001, return_correspondences=True)
+    b = icp_batch(flat, off, tgt, toff, init, epsilon=0.001, return_correspondences=True, prune=True)
+    np.testing.assert_array_equal(b.iterations, a.iterations)
+    np.testing.assert_array_equal(b.correspondences, a.correspondences)
+    np.testing.assert_allclose(b.T, a.T, atol=1e-11)
+    np.testing.assert_allclose(b.error, a.error, rtol=1e-11)
+
+    rng = np.random.default_rng(77)
+    sizes = [(8, 6), (100, 3000), (4096, 4096), (3000, 700), (1081, 1081), (4000, 64), (513, 4096)]
+    ss, ts = [], []
+    for n, m in sizes:
+        s_, t_ = _random_problem(rng, 2, n, m, spread=rng.uniform(0.5, 20.0))
+        if m > 40:
+            t_[m // 2] = t_[3]; t_[m - 1] = t_[3]          # exact duplicates far apart in index
+        ss.append(s_); ts.append(t_)
+    fs, so = pack_clouds(ss)
+    ft, to = pack_clouds(ts)
+    I = np.tile(np.eye(4), (len(sizes), 1, 1))
+    for norm in (False, True):
+        a = icp_batch(fs, so, ft, to, I, epsilon=1e-12, max_iters=12, normalize_error=norm, return_correspondences=True)
+        b = icp_batch(fs, so, ft, to, I, epsilon=1e-12, max_iters=12, normalize_error=norm, return_correspondences=True, prune=True)
+        np.testing.assert_array_equal(b.iterations, a.iterations)
+        np.testing.assert_array_equal(b.correspondences, a.correspondences)
+        np.testing.assert_allclose(b.T, a.T, atol=1e-10)
+
+    w = batch_c4(24, 4096, seed=5)                           # the benchmark's shape
+    a = icp_batch(w.src, w.src_off, w.tgt, w.tgt_off, w.init_T, epsilon=0.0, stopping_thresh=0.0, max_iters=9, return_correspondences=True)
+    b = icp_batch(w.src, w.src_off, w.tgt, w.tgt_off, w.init_T, epsilon=0.0, stopping_thresh=0.0, max_iters=9, return_correspondences=True, prune=True)
+    np.testing.assert_array_equal(b.correspondences, a.correspondences)
+    np.testing.assert_allclose(b.T, a.T, atol=1e-11)
+
+    # above the size limit the flag is ignored (plain sweep), not an error
+    s_, t_ = _random_problem(rng, 2, 5000, 5000, 3.0)
+    a = icp_batch(*pack_clouds([s_]), *pack_clouds([t_]), np.eye(4)[None], max_iters=3, epsilon=1e-12, return_correspondences=True)
+    b = icp_batch(*pack_clouds([s_]), *pack_clouds([t_]), np.eye(4)[None], max_iters=3, epsilon=1e-12, return_correspondences=True, prune=True)
+    np.testing.assert_array_equal(b.correspondences, a.correspondences)
+    np.testing.assert_array_equal(b.T, a.T)
