@@ -231,6 +231,13 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
             const float2 q = tile[pv];
             best[p] = dist2(ax[p], ay[p], q.x, q.y);
             bchunk[p] = pv / CHUNK;
+          } else {
+            // first iteration: both clouds are sorted along the same curve, so the target at the same
+            // relative rank is usually close — any evaluated point is a valid upper bound
+            const int g = (int)(((long long)i * m) / n);
+            const float2 q = tile[g];
+            best[p] = dist2(ax[p], ay[p], q.x, q.y);
+            bchunk[p] = g / CHUNK;
           }
         }
       }
