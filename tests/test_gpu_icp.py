@@ -369,3 +369,35 @@ def test_exact_pruning_gives_the_brute_force_answers(icp):
     b = icp_batch(*pack_clouds([s_]), *pack_clouds([t_]), np.eye(4)[None], max_iters=3, epsilon=1e-12, return_correspondences=True, prune=True)
     np.testing.assert_array_equal(b.correspondences, a.correspondences)
     np.testing.assert_array_equal(b.T, a.T)
+
+
+def test_pruning_on_degenerate_clouds_with_massive_ties(icp):
+    """lattices, coincident points, a cloud collapsed to one point: every tie must still resolve to the
+    lowest ORIGINAL index, exactly as the all-pairs sweep does"""
+    from lidar_slam_amd.batch import icp_batch, pack_clouds
+    rng = np.random.default_rng(5)
+    gx, gy = np.meshgrid(np.arange(40) * 0.25, np.arange(40) * 0.25)
+    lattice = np.column_stack((gx.ravel(), gy.ravel()))                      # 1600 points, exact ties everywhere
+    shuffled = lattice[rng.permutation(lattice.shape[0])]
+    cases = [
+        (lattice + 0.125, shuffled),                                          # sources at cell centres: 4-way ties
+        (shuffled[:700], np.vstack((lattice, lattice[::-1]))),                # every target duplicated
+        (rng.normal(size=(500, 2)), np.tile([[1.5, -2.0]], (300, 1))),        # target collapsed to one point
+        (np.tile([[0.3, 0.3]], (200, 1)), lattice),                           # source collapsed to one point
+        (lattice[:64], lattice[:64]),                                         # identical clouds
+    ]
+    fs, so = pack_clouds([c[0] for c in cases])
+    ft, to = pack_clouds([c[1] for c in cases])
+    I = np.tile(np.eye(4), (len(cases), 1, 1))
+    a = icp_batch(fs, so, ft, to, I, epsilon=1e-30, max_iters=2, return_correspondences=True)
+    b = icp_batch(fs, so, ft, to, I, epsilon=1e-30, max_iters=2, return_correspondences=True, prune=True)
+    np.testing.assert_array_equal(b.correspondences, a.correspondences)
+    np.testing.assert_array_equal(b.iterations, a.iterations)
+    ok = np.isfinite(a.T).all(axis=(1, 2))
+    np.testing.assert_allclose(b.T[ok], a.T[ok], atol=1e-9)
+    # first iteration of case 0 against a direct evaluation: lowest index among the 4 equidistant corners
+    s32, t32 = (lattice + 0.125).astype(np.float32), shuffled.astype(np.float32)
+    one = icp_batch(s32, [0, 1600], t32, [0, 1600], np.eye(4)[None], epsilon=0.0, max_iters=0, stopping_thresh=0.0,
+                    return_correspondences=True, prune=True)
+    d = ((s32[:, None, :] - t32[None, :, :]) ** 2).sum(-1)
+    np.testing.assert_array_equal(one.correspondences, np.argmin(d, axis=1))
