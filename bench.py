@@ -363,12 +363,18 @@ def other_config(name, a, torch, device, stream, timed):
                                        stopping_thresh=0.0, poll_every=20, stream=stream)
         ms = _time(torch, run, 2, 3)
         T, err, it = res["r"]
+        def run_pruned():
+            res["p"] = B.icp_large_dev(s.data_ptr(), s.shape[0], t.data_ptr(), t.shape[0], 3, T0, epsilon=0.0, max_iters=19,
+                                       stopping_thresh=0.0, poll_every=20, stream=stream, prune=True)
+        ms_p = _time(torch, run_pruned, 2, 3)
         out = {"workload": "C5 dense 3-D 100k x 100k, 20 forced iterations, whole chip", "ms": ms, "iterations": it,
                "iterations_per_sec": it / (ms * 1e-3), "pair_evals_per_sec": it * 1e10 / (ms * 1e-3),
                "roofline": {"kernel": "nn_tiled_kernel<3,4> (+ moments_kernel<3>, solve_kernel<3> per iteration)", "bound": "valu",
                             "achieved": it * 1e10 * 8 / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                             "frac": it * 1e10 * 8 / (ms * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
                             "note": "8 algorithmic flop per 3-D pair evaluation; whole iteration (3 launches) timed, not the search kernel alone"},
+               "pruned": {"what": "same 20 iterations with LSLAM_ICP_PRUNE (Morton sort + box hierarchy, exact results; the sort is inside the timed call)",
+                          "ms": ms_p, "speedup": ms / ms_p, "max_abs_T_difference": float(np.abs(res["p"][0] - T).max())},
                "pose_err_vs_truth": float(np.abs(T - T_true).max())}
     elif name == "c3":
         from lidar_slam_amd.modules.localization import scan_matching_relative_poses, chain_poses

@@ -281,6 +281,43 @@ struct LargeWs {
   }
 };
 LargeWs& large_ws() { static thread_local LargeWs w; return w; }
+
+// workspace of the pruned whole-chip path: one arena block carved into the LpWs arrays
+struct LpHolder {
+  int device = -1;
+  void* block = nullptr; size_t cap = 0;
+  int ensure(int dev, int dim, int64_t n, int64_t m, LpWs* ws) {
+    const int64_t mx = n > m ? n : m;
+    const size_t pt = dim == 2 ? sizeof(float2) : sizeof(float4);
+    const int CH = dim == 2 ? NnChunk<2>::value : NnChunk<3>::value;
+    const int64_t n1 = (m + CH - 1) / CH, n2 = (n1 + 63) / 64, n3 = (n2 + 63) / 64;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    ws->temp_bytes = lp_sort_temp_bytes(mx);
+    const size_t need = al(pt * n) + al(4 * n) + al(pt * m) + al(4 * m) + 2 * (al(16 * n1) + al(16 * n2) + al(16 * n3)) + al(4 * n) +
+                        4 * al(4 * mx) + al(4 * 6 * 1024) + al(64) + al(ws->temp_bytes);
+    if (dev != device || need > cap) {
+      if (block) { (void)hipDeviceSynchronize(); (void)hipFree(block); }
+      block = nullptr; cap = 0; device = dev;
+      LSLAM_HIP_TRY(hipMalloc(&block, need + (need >> 3)));
+      cap = need + (need >> 3);
+    }
+    char* p = static_cast<char*>(block);
+    auto take = [&](size_t b) { void* r = p; p += al(b); return r; };
+    ws->src_sorted = take(pt * n); ws->src_index = static_cast<int32_t*>(take(4 * n));
+    ws->tgt_sorted = take(pt * m); ws->tgt_index = static_cast<int32_t*>(take(4 * m));
+    ws->lo1 = static_cast<float4*>(take(16 * n1)); ws->hi1 = static_cast<float4*>(take(16 * n1));
+    ws->lo2 = static_cast<float4*>(take(16 * n2)); ws->hi2 = static_cast<float4*>(take(16 * n2));
+    ws->lo3 = static_cast<float4*>(take(16 * n3)); ws->hi3 = static_cast<float4*>(take(16 * n3));
+    ws->match = static_cast<int32_t*>(take(4 * n));
+    ws->keys_in = static_cast<unsigned*>(take(4 * mx)); ws->keys_out = static_cast<unsigned*>(take(4 * mx));
+    ws->vals_in = static_cast<unsigned*>(take(4 * mx)); ws->vals_out = static_cast<unsigned*>(take(4 * mx));
+    ws->bbox_partial = static_cast<float*>(take(4 * 6 * 1024));
+    ws->grid = static_cast<float*>(take(64));
+    ws->temp = take(ws->temp_bytes);
+    return LSLAM_OK;
+  }
+};
+LpHolder& lp_holder() { static thread_local LpHolder h; return h; }
 }  // namespace
 }  // extern "C++"
 
@@ -298,10 +335,18 @@ int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64
   int dev = 0;
   LSLAM_HIP_TRY(hipGetDevice(&dev));
   LargeWs& ws = large_ws();
+  bool prune = (flags & kFlagPrune) != 0;
+  if (const char* e = getenv("LSLAM_ICP_PRUNE")) prune = atoi(e) != 0;
   const NnGeometry geo = nn_geometry(dim, n, m);
-  int rc = ws.ensure(dev, n * geo.splits);
+  int rc = ws.ensure(dev, prune ? 1 : n * geo.splits);
   if (rc != LSLAM_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  LpWs lp{};
+  LpTree tree{};
+  if (prune) {
+    if ((rc = lp_holder().ensure(dev, dim, n, m, &lp)) != LSLAM_OK) return rc;
+    LSLAM_HIP_TRY(lp_prepare(dim, d_src, n, d_tgt, m, init_T, lp, &tree, st));
+  }
 
   LargeState* hs = ws.h_state;
   memcpy(hs->T, init_T, sizeof(double) * 16);
@@ -325,8 +370,20 @@ int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64
   int64_t launched = 0;
   for (;;) {
     for (int k = 0; k < poll_every && launched < cap; ++k, ++launched) {
-      LSLAM_HIP_TRY(launch_nn(na, dim, geo, st));
-      LSLAM_HIP_TRY(launch_moments(ma, dim, rows, st));
+      if (prune) {
+        LpNnArgs pa{};
+        pa.src_sorted = lp.src_sorted; pa.n = n; pa.tgt_sorted = lp.tgt_sorted; pa.tgt_index = lp.tgt_index; pa.m = m;
+        pa.lo1 = lp.lo1; pa.hi1 = lp.hi1; pa.lo2 = lp.lo2; pa.hi2 = lp.hi2; pa.lo3 = lp.lo3; pa.hi3 = lp.hi3;
+        pa.n1 = tree.n1; pa.n2 = tree.n2; pa.n3 = tree.n3; pa.match = lp.match; pa.state = ws.state;
+        LpMomArgs pm{};
+        pm.src_sorted = lp.src_sorted; pm.src_index = lp.src_index; pm.n = n; pm.tgt_sorted = lp.tgt_sorted; pm.tgt_index = lp.tgt_index;
+        pm.match = lp.match; pm.state = ws.state; pm.partials = ws.partials; pm.out_corr = d_out_corr; pm.flags = flags;
+        LSLAM_HIP_TRY(lp_launch_nn(dim, pa, st));
+        LSLAM_HIP_TRY(lp_launch_moments(dim, pm, rows, st));
+      } else {
+        LSLAM_HIP_TRY(launch_nn(na, dim, geo, st));
+        LSLAM_HIP_TRY(launch_moments(ma, dim, rows, st));
+      }
       LSLAM_HIP_TRY(launch_solve(sa, dim, st));
     }
     LSLAM_HIP_TRY(hipMemcpyAsync(hs, ws.state, sizeof(LargeState), hipMemcpyDeviceToHost, st));

@@ -134,6 +134,42 @@ int moments_rows(int64_t n);
 hipError_t launch_moments(MomArgs a, int dim, int rows, hipStream_t stream);
 hipError_t launch_solve(SolveArgs a, int dim, hipStream_t stream);
 
+// ---- whole-chip path with exact box pruning (lslam_icp_large_pruned.hip) ------------------------------
+struct LpT { float m[3][4]; };
+struct LpWs {                      // device workspace of one problem
+  void* src_sorted; int32_t* src_index;        // float2 / float4 per point, original index
+  void* tgt_sorted; int32_t* tgt_index;
+  float4 *lo1, *hi1, *lo2, *hi2, *lo3, *hi3;   // box hierarchy over the sorted target
+  int32_t* match;                              // per sorted source: sorted target position of its last match
+  unsigned *keys_in, *keys_out, *vals_in, *vals_out;
+  float* bbox_partial;                         // 1024 x 6
+  float* grid;                                 // lo[3], scale[3]
+  void* temp; size_t temp_bytes;
+};
+struct LpTree { int64_t n1, n2, n3; };
+struct LpNnArgs {
+  const void* src_sorted; int64_t n;
+  const void* tgt_sorted; const int32_t* tgt_index; int64_t m;
+  const float4 *lo1, *hi1, *lo2, *hi2, *lo3, *hi3;
+  int64_t n1, n2, n3;
+  int32_t* match;
+  const LargeState* state;
+};
+struct LpMomArgs {
+  const void* src_sorted; const int32_t* src_index; int64_t n;
+  const void* tgt_sorted; const int32_t* tgt_index;
+  const int32_t* match;
+  const LargeState* state;
+  double* partials;
+  int32_t* out_corr;
+  uint32_t flags;
+};
+size_t lp_sort_temp_bytes(int64_t n);
+hipError_t lp_prepare(int dim, const float* d_src, int64_t n, const float* d_tgt, int64_t m, const double* init_T,
+                      const LpWs& ws, LpTree* tree, hipStream_t st);
+hipError_t lp_launch_nn(int dim, const LpNnArgs& a, hipStream_t st);
+hipError_t lp_launch_moments(int dim, const LpMomArgs& a, int rows, hipStream_t st);
+
 // ---- float64 pair operators (lslam_ops.hip) -------------------------------------------------------
 struct PairOpArgs {
   const double* p; int64_t p_stride;
