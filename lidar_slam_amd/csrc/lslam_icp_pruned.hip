@@ -265,6 +265,16 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
 #pragma unroll
           for (int p = 0; p < P; ++p) need |= best[p] >= lb;
           if (!__any(need)) continue;                      // nothing in this chunk can beat or tie any lane
+          // second look with every lane's OWN points: the sorted sources of a wave sit on a Morton curve
+          // that sometimes jumps across the cloud; the wave's box is then large, each point's reach is not
+          bool need_own = false;
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            const float ox = fmaxf(fmaxf(b.x - ax[p], ax[p] - b.z), 0.f);
+            const float oy = fmaxf(fmaxf(b.y - ay[p], ay[p] - b.w), 0.f);
+            need_own |= best[p] >= __builtin_fmaf(oy, oy, ox * ox) * kPruneSafety;
+          }
+          if (!__any(need_own)) continue;
           float4 v[CHUNK / 2];
 #pragma unroll
           for (int k = 0; k < CHUNK / 2; ++k) v[k] = t4[c * (CHUNK / 2) + k];
