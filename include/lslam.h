@@ -76,10 +76,11 @@ int         lslam_valu_probe(int device, double *out_lane_ops_per_s);
  *   flags      LSLAM_ICP_* bits
  */
 #define LSLAM_ICP_NORMALIZE_ERROR 1u   /* icp.py:91-97 */
-/* Opt-in (planar problems of at most 4096 points per cloud; ignored otherwise): put both clouds into
- * Morton order once per problem and skip, with an exact float32-safe bound, every 16-point target
- * chunk that cannot hold a nearer point for any source of a wave.  Same correspondences, iteration
- * counts and (to float64 summation order) transforms as the plain all-pairs sweep. */
+/* Opt-in exact pruning: put both clouds into Morton order once per problem and skip, with a
+ * float32-safe bound, every group of target points whose bounding box cannot hold a nearer (or equally
+ * near) point for any source of a wave.  Same correspondences, iteration counts and (to float64
+ * summation order) transforms as the plain all-pairs sweep.  Batched entry points: planar problems of
+ * at most 4096 points per cloud (ignored otherwise); lslam_icp_large*: any size, planar or 3-D. */
 #define LSLAM_ICP_PRUNE 2u
 
 int lslam_icp_batch(const float *src, const int64_t *src_off,
