@@ -245,9 +245,12 @@ nn_pruned_kernel(LpNnArgs a) {
   auto test64 = [&](const float4* __restrict__ lo, const float4* __restrict__ hi, int64_t first, int64_t total, float wmax,
                     float& my_lb, float4& my_lo, float4& my_hi) -> unsigned long long {
     my_lb = INFINITY;
+    my_lo = make_float4(0.f, 0.f, 0.f, 0.f);
+    my_hi = my_lo;
     const int64_t b = first + lane;
-    if (b < total) { my_lo = lo[b]; my_hi = hi[b]; my_lb = box_bound(my_lo, my_hi); }
-    return __ballot(my_lb <= wmax);
+    const bool real = b < total;
+    if (real) { my_lo = lo[b]; my_hi = hi[b]; my_lb = box_bound(my_lo, my_hi); }
+    return __ballot(real && my_lb <= wmax);                  // (wmax is +inf while a lane has no candidate yet)
   };
   // stage 2 — one candidate box (held by lane k) against every lane's OWN points and OWN best: the
   // 64·P sources of a wave are consecutive on a Morton curve, which now and then jumps across the
