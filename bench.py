@@ -399,7 +399,19 @@ def other_config(name, a, torch, device, stream, timed):
     return out
 
 
+def _warm_gpu(seconds=0.25):
+    """the chip clocks down during the CPU-only legs of this script (baselines, synthesis): spin the VALUs
+    for a moment before a short timed region so that it is measured at the sustained clock"""
+    import ctypes
+    from lidar_slam_amd._lib import lib
+    v = ctypes.c_double(0.0)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        lib().lslam_valu_probe(0, ctypes.byref(v))
+
+
 def _time(torch, fn, warm, reps):
+    _warm_gpu()
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
