@@ -401,3 +401,14 @@ def test_pruning_on_degenerate_clouds_with_massive_ties(icp):
                     return_correspondences=True, prune=True)
     d = ((s32[:, None, :] - t32[None, :, :]) ** 2).sum(-1)
     np.testing.assert_array_equal(one.correspondences, np.argmin(d, axis=1))
+
+
+def test_module_switch_for_pruning_keeps_run_icp_results(icp, monkeypatch):
+    g = golden("icp_3d.npz")
+    ref = icp.run_icp(g["src"], g["tgt"], g["init"][1], 0.001, return_error=True, normalize_error=True, return_correspondences=True)
+    monkeypatch.setattr(icp, "PRUNE", True)
+    got = icp.run_icp(g["src"], g["tgt"], g["init"][1], 0.001, return_error=True, normalize_error=True, return_correspondences=True)
+    np.testing.assert_array_equal(got[2], ref[2])
+    np.testing.assert_allclose(got[0], ref[0], atol=1e-11)
+    np.testing.assert_allclose(got[1], ref[1], rtol=1e-10)
+    close_to_reference(got[0], g["T"][1])
