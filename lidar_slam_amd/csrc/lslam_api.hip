@@ -353,10 +353,18 @@ int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64
   hs->err = 0.0;
   stop_init(hs->stop);
   hs->done = 0;
+  hs->ticket = 0;
   LSLAM_HIP_TRY(hipMemcpyAsync(ws.state, hs, sizeof(LargeState), hipMemcpyHostToDevice, st));
 
   NnArgs na{};
   na.src = d_src; na.n = n; na.tgt = d_tgt; na.m = m; na.keys = ws.keys; na.state = ws.state;
+  bool fuse = !prune && geo.P == 1;                         // small problem: one launch per iteration
+  if (const char* e = getenv("LSLAM_ICP_FUSE_TAIL")) fuse = fuse && atoi(e) != 0;
+  if (fuse) {
+    na.fuse_state = ws.state; na.out_corr = d_out_corr; na.splits = geo.splits; na.flags = flags;
+    na.epsilon = epsilon; na.stopping_thresh = stopping_thresh; na.max_iters = max_iters;
+    LSLAM_HIP_TRY(hipMemsetAsync(ws.keys, 0xff, sizeof(unsigned long long) * n, st));   // neutral keys for the atomic mins
+  }
   MomArgs ma{};
   ma.src = d_src; ma.n = n; ma.tgt = d_tgt; ma.keys = ws.keys; ma.splits = geo.splits; ma.state = ws.state; ma.partials = ws.partials;
   ma.out_corr = d_out_corr; ma.flags = flags;
@@ -382,6 +390,7 @@ int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64
         LSLAM_HIP_TRY(lp_launch_moments(dim, pm, rows, st));
       } else {
         LSLAM_HIP_TRY(launch_nn(na, dim, geo, st));
+        if (fuse) continue;                                 // the search kernel's last workgroup did the rest
         LSLAM_HIP_TRY(launch_moments(ma, dim, rows, st));
       }
       LSLAM_HIP_TRY(launch_solve(sa, dim, st));

@@ -23,7 +23,17 @@ namespace lslam {
 
 constexpr unsigned long long kKeyInit = ~0ull;
 
-template <int DIM, int P>
+// min over the split rows of the keys (exact argmin, lowest index on ties)
+__device__ __forceinline__ unsigned long long reduce_keys(const unsigned long long* keys, int64_t n, int splits, int64_t i) {
+  unsigned long long k = keys[i];
+  for (int s = 1; s < splits; ++s) {
+    const unsigned long long v = keys[(int64_t)s * n + i];
+    k = v < k ? v : k;
+  }
+  return k;
+}
+
+template <int DIM, int P, bool FUSE>
 __global__ void __launch_bounds__(kNnThreads)
 nn_tiled_kernel(NnArgs a) {
   constexpr int CHUNK = NnChunk<DIM>::value;
@@ -133,20 +143,15 @@ nn_tiled_kernel(NnArgs a) {
     }
   }
   unsigned long long* __restrict__ keys = a.keys + (int64_t)blockIdx.y * a.n;   // this split's row
-  if (c_begin >= c_end) {                                   // empty split: neutral keys
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int64_t i = base + (int64_t)p * kNnThreads + tid;
-      if (i < a.n) keys[i] = kKeyInit;
-    }
-    return;
-  }
-
   // ---- fix-up from global memory (the winning chunk may have left LDS) + store -------------------
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int64_t i = base + (int64_t)p * kNnThreads + tid;
     if (i >= a.n) continue;
+    if (c_begin >= c_end) {                                  // empty split: neutral key
+      if constexpr (!FUSE) keys[i] = kKeyInit;
+      continue;
+    }
     const int64_t j0 = (int64_t)bchunk[p] * CHUNK;
     float bd = INFINITY;
     int64_t bi = j0;
@@ -165,18 +170,81 @@ nn_tiled_kernel(NnArgs a) {
       }
       if (d < bd || k == 0) { bd = d; bi = j; }
     }
-    keys[i] = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(uint32_t)bi;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(uint32_t)bi;
+    if constexpr (FUSE) atomicMin(&a.keys[i], key);         // one key row shared by the splits (reset by the tail)
+    else keys[i] = key;
   }
-}
 
-// min over the split rows of the keys (exact argmin, lowest index on ties)
-__device__ __forceinline__ unsigned long long reduce_keys(const unsigned long long* keys, int64_t n, int splits, int64_t i) {
-  unsigned long long k = keys[i];
-  for (int s = 1; s < splits; ++s) {
-    const unsigned long long v = keys[(int64_t)s * n + i];
-    k = v < k ? v : k;
+  // ---- fused tail for small problems ---------------------------------------------------------------
+  // Every workgroup takes a ticket once its keys are stored (stores → workgroup barrier → agent-scope
+  // release → atomic); the one that draws the last ticket acquires and finishes the iteration alone.
+  if constexpr (FUSE) {
+  __shared__ int sh_last;
+  __shared__ double sh_acc[kNnThreads / 64][AccLayout<DIM>::kTotal];
+  __syncthreads();                                          // all key stores of this workgroup are issued and waited for
+  if (tid == 0) {
+    __threadfence();                                        // release (agent scope)
+    const int total = (int)(gridDim.x * gridDim.y);
+    sh_last = (atomicAdd(&a.fuse_state->ticket, 1) == total - 1) ? 1 : 0;
+    if (sh_last) __threadfence();                           // acquire: the other workgroups' keys
   }
-  return k;
+  __syncthreads();
+  if (!sh_last) return;
+
+  constexpr int kAcc = AccLayout<DIM>::kTotal;
+  const bool box = (a.flags & kFlagNormalize) != 0;
+  PairAcc<DIM> acc;
+  acc.clear();
+  constexpr int U = 4;                                      // keys, then points, of U sources in flight per thread
+  for (int64_t i0 = tid; i0 < a.n; i0 += (int64_t)U * kNnThreads) {
+    uint32_t j[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * kNnThreads;
+      j[u] = (i < a.n) ? (uint32_t)(a.keys[i] & 0xffffffffull) : 0u;
+    }
+    double pp[U][DIM], qq[U][DIM];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * kNnThreads;
+      if (i >= a.n) continue;
+      a.keys[i] = kKeyInit;                                 // ready for the next iteration's atomic mins
+      if (a.out_corr) a.out_corr[i] = (int32_t)j[u];
+      const double x = a.src[DIM * i], y = a.src[DIM * i + 1];
+      double z = 0.0;
+      if constexpr (DIM == 3) z = a.src[DIM * i + 2];
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) {
+        double v = T[r][0] * x + T[r][1] * y + T[r][3];
+        if constexpr (DIM == 3) v += T[r][2] * z;
+        pp[u][r] = v;
+        qq[u][r] = (double)a.tgt[DIM * (int64_t)j[u] + r];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + (int64_t)u * kNnThreads < a.n) acc.add(pp[u], qq[u], box);
+  }
+  acc.wave_reduce(box);
+  if ((tid & 63) == 0) acc.store(sh_acc[tid >> 6]);
+  __syncthreads();
+  if (tid != 0) return;
+  Moments mo;
+  combine_partials<DIM>(&sh_acc[0][0], kNnThreads / 64, kAcc, box, mo);
+  LargeState* st = a.fuse_state;
+  double Tstep[16], Tprev[16], Tnew[16];
+  step_from_moments(mo, DIM == 2, Tstep);
+  for (int i = 0; i < 16; ++i) Tprev[i] = st->T[i];
+  matmul4(Tstep, Tprev, Tnew);
+  for (int i = 0; i < 16; ++i) st->T[i] = Tnew[i];
+  const double err = error_from_moments(mo, box);
+  st->err = err;
+  StopState ss = st->stop;
+  const bool stop = stop_after_iteration(ss, err, a.epsilon, a.stopping_thresh, a.max_iters);
+  st->stop = ss;
+  if (stop) st->done = 1;
+  st->ticket = 0;                                           // ready for the next launch
+  }
 }
 
 // keys → (index, d²).  Used by the NN-only entry point.
@@ -307,14 +375,17 @@ hipError_t launch_nn(NnArgs a, int dim, const NnGeometry& g, hipStream_t stream)
   a.chunks_per_split = g.chunks_per_split;
   if (a.n <= 0) return hipSuccess;
   const dim3 grid(g.grid_x, (unsigned)g.splits), block(kNnThreads);
+  const bool fuse = a.fuse_state != nullptr;                // the caller sets it only when g.P == 1
   if (dim == 2) {
-    if (g.P == 1) hipLaunchKernelGGL((nn_tiled_kernel<2, 1>), grid, block, g.smem, stream, a);
-    else if (g.P == 2) hipLaunchKernelGGL((nn_tiled_kernel<2, 2>), grid, block, g.smem, stream, a);
-    else hipLaunchKernelGGL((nn_tiled_kernel<2, 4>), grid, block, g.smem, stream, a);
+    if (fuse) hipLaunchKernelGGL((nn_tiled_kernel<2, 1, true>), grid, block, g.smem, stream, a);
+    else if (g.P == 1) hipLaunchKernelGGL((nn_tiled_kernel<2, 1, false>), grid, block, g.smem, stream, a);
+    else if (g.P == 2) hipLaunchKernelGGL((nn_tiled_kernel<2, 2, false>), grid, block, g.smem, stream, a);
+    else hipLaunchKernelGGL((nn_tiled_kernel<2, 4, false>), grid, block, g.smem, stream, a);
   } else {
-    if (g.P == 1) hipLaunchKernelGGL((nn_tiled_kernel<3, 1>), grid, block, g.smem, stream, a);
-    else if (g.P == 2) hipLaunchKernelGGL((nn_tiled_kernel<3, 2>), grid, block, g.smem, stream, a);
-    else hipLaunchKernelGGL((nn_tiled_kernel<3, 4>), grid, block, g.smem, stream, a);
+    if (fuse) hipLaunchKernelGGL((nn_tiled_kernel<3, 1, true>), grid, block, g.smem, stream, a);
+    else if (g.P == 1) hipLaunchKernelGGL((nn_tiled_kernel<3, 1, false>), grid, block, g.smem, stream, a);
+    else if (g.P == 2) hipLaunchKernelGGL((nn_tiled_kernel<3, 2, false>), grid, block, g.smem, stream, a);
+    else hipLaunchKernelGGL((nn_tiled_kernel<3, 4, false>), grid, block, g.smem, stream, a);
   }
   return hipGetLastError();
 }

@@ -86,6 +86,7 @@ struct LargeState {          // lives in device memory for the whole run of one 
   double err;
   StopState stop;
   int32_t done;
+  int32_t ticket;                // arrival counter of the fused small-problem iteration (0 between launches)
 };
 
 struct NnArgs {
@@ -96,6 +97,14 @@ struct NnArgs {
   double T[16];
   int32_t tile_points;           // filled by the launcher
   int64_t chunks_per_split;      // filled by the launcher
+  // fused tail (small problems): the last workgroup to finish also reduces the keys, accumulates the
+  // moments, solves and applies the stop rules — one launch per iteration instead of three
+  LargeState* fuse_state;        // nullptr = no fused tail
+  int32_t* out_corr;
+  int32_t splits;
+  uint32_t flags;
+  double epsilon, stopping_thresh;
+  int32_t max_iters;
 };
 
 struct NnGeometry {
