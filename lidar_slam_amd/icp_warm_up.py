@@ -1,0 +1,75 @@
+"""Multi-start registration of the reference's ICP drill (code/icp_warm_up/test_icp.py:66-92) on MI355X.
+
+The reference aligns a canonical object model to each measured cloud by running ``run_icp`` from 24
+yaw starts (rotation about z, translation matching the centroids) and keeping the start with the
+lowest normalised error; clouds above 20 000 points are voxel-downsampled (5 mm) first.  Here the
+starts of one target are ONE batched launch (one workgroup per start, clouds shared through the
+same device buffers) when the clouds are small, and back-to-back whole-chip runs when they are
+not; the best-of rule, the arguments of ``run_icp`` and the returned quantities are the reference's.
+File loading and plotting of the reference script are out of scope.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ._lib import ICP_NORMALIZE_ERROR, check, lib, ptr
+from .batch import icp_batch
+from .modules import icp
+
+# above this many pair evaluations per iteration one start keeps the whole chip busy by itself
+SEQUENTIAL_PAIR_EVALS = 2_000_000
+
+
+def T_from_yaw(yaw):
+    """4x4 rotation about z (test_icp.py:44-50)"""
+    c, s = np.cos(yaw), np.sin(yaw)
+    return np.array([[c, -s, 0.0, 0.0], [s, c, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+
+
+def yaw_starts(source_pc, target_pc, n_starts=24):
+    """The initial transforms of test_icp.py:70-74: yaw k·2π/n about z, translation such that the rotated
+    source centroid lands on the target centroid.  Returns (n_starts, 4, 4) float64."""
+    src = np.asarray(source_pc, dtype=np.float64)
+    tgt = np.asarray(target_pc, dtype=np.float64)
+    a, b = np.mean(src, axis=0), np.mean(tgt, axis=0)
+    T = np.stack([T_from_yaw(y) for y in np.linspace(0, 2 * np.pi, n_starts, endpoint=False)])
+    T[:, 0:3, 3] = b[None, :] - np.einsum("kij,j->ki", T[:, 0:3, 0:3], a)
+    return T
+
+
+def register_multi_start(source_pc, target_pc, n_starts=24, epsilon=0.001, voxel_size=0.005,
+                         downsample_above=20000, max_iters=2000, stopping_thresh=0.0001,
+                         return_all=False):
+    """Best pose of ``n_starts`` yaw-started ICP runs (test_icp.py:66-92).
+
+    Returns ``(best_pose (4,4) f64, best_error np.float64)`` — the first start reaching the lowest
+    error wins, as the reference's ``err < best_error`` scan does — and with ``return_all`` also
+    ``(poses (S,4,4), errors (S,), iterations (S,))`` of every start.
+    """
+    source_pc = np.asarray(source_pc)
+    target_pc = np.asarray(target_pc)
+    init = yaw_starts(source_pc, target_pc, n_starts)          # centroids of the FULL clouds (test_icp.py:72-74)
+    if source_pc.shape[0] > downsample_above or target_pc.shape[0] > downsample_above:
+        src, tgt = icp.voxel_downsample(source_pc, voxel_size), icp.voxel_downsample(target_pc, voxel_size)
+    else:
+        src, tgt = source_pc, target_pc
+    n, m, S = src.shape[0], tgt.shape[0], init.shape[0]
+    d = 2 if (src.shape[1] == 2 and tgt.shape[1] == 2) else 3
+    s32 = np.ascontiguousarray(icp._xyz(src)[:, :d], dtype=np.float32)
+    t32 = np.ascontiguousarray(icp._xyz(tgt)[:, :d], dtype=np.float32)
+    if n * m > SEQUENTIAL_PAIR_EVALS:
+        poses, errors, iters = np.empty((S, 4, 4)), np.empty(S), np.zeros(S, dtype=np.int32)
+        for k in range(S):
+            check(lib().lslam_icp_large(ptr(s32), n, ptr(t32), m, d, ptr(np.ascontiguousarray(init[k])), float(epsilon),
+                                        float(stopping_thresh), int(max_iters), ICP_NORMALIZE_ERROR, ptr(poses[k]),
+                                        ptr(errors[k:k + 1]), ptr(iters[k:k + 1]), None, icp._DEVICE))
+    else:
+        r = icp_batch(np.tile(s32, (S, 1)), np.arange(S + 1, dtype=np.int64) * n, np.tile(t32, (S, 1)),
+                      np.arange(S + 1, dtype=np.int64) * m, init, epsilon=epsilon, max_iters=max_iters,
+                      stopping_thresh=stopping_thresh, normalize_error=True, device=icp._DEVICE)
+        poses, errors, iters = r.T, r.error, r.iterations
+    best = int(np.argmin(errors))                                # argmin = first index of the minimum = the reference's strict <
+    out = (poses[best].copy(), np.float64(errors[best]))
+    if return_all:
+        out += (poses, errors, iters)
+    return out

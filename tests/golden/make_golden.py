@@ -11,6 +11,7 @@ What is captured (SURVEY §8(c) G1–G8):
   icp_forced50.npz  G2  2 of them with exactly 50 iterations (eps=0, thresh=0, max_iters=49)
   icp_loopclose.npz G3  identity init, normalize_error=True, default eps (main.py:162 style)
   icp_3d.npz        G4  synthetic 3-D object, partial view, 4 of the 24 yaw starts of test_icp.py:70-88
+  icp_multistart.npz G4' all 24 yaw starts on the clouds of icp_3d.npz + the best-of pick (make_golden_multistart.py)
   kabsch.npz        G5  get_transform alone: planar (incl. reflections), 3-D, single point
   seq_scanmatch.npz G6  32-scan poses_from_scan_matching sequence
   ogm_main.npz      G7  main.py grid geometry (res .05, ±30 m): integer hit/miss grids + float log-odds

@@ -109,6 +109,37 @@ def test_3d_multistart_vs_golden_and_oracle(icp):
         np.testing.assert_allclose(r.error[k], eo, rtol=1e-9)
 
 
+@pytest.mark.parametrize("sequential", [False, True])
+def test_register_multi_start_matches_reference_loop(icp, sequential, monkeypatch):
+    """24 yaw starts of code/icp_warm_up/test_icp.py:66-92: one batched launch, or whole-chip runs back to back"""
+    from lidar_slam_amd import icp_warm_up as W
+    g, m = golden("icp_3d.npz"), golden("icp_multistart.npz")
+    if sequential:
+        monkeypatch.setattr(W, "SEQUENTIAL_PAIR_EVALS", 0)
+    from oracle import icp_oracle
+    pose, err, poses, errors, iters = W.register_multi_start(g["src"], g["tgt"], return_all=True)
+    np.testing.assert_array_equal(iters, m["iterations"])
+    init = W.yaw_starts(g["src"], g["tgt"])
+    r32 = lambda a: a.astype(np.float32).astype(np.float64)
+    sensitive = 0
+    for k in range(24):
+        if np.abs(poses[k][:3, :3] - m["T"][k][:3, :3]).max() < TOL_ROT:
+            close_to_reference(poses[k], m["T"][k])
+            assert abs(errors[k] - m["error"][k]) < 2e-5 * m["error"][k]
+            continue
+        # a wrong-basin start where rounding the INPUT clouds to float32 flips a correspondence: the float64
+        # restatement fed the rounded clouds leaves the reference by the same amount, and the device follows it
+        sensitive += 1
+        o = icp_oracle.run_icp_full(r32(g["src"]), r32(g["tgt"]), init[k], epsilon=0.001, normalize_error=True)
+        assert np.abs(o.T[:3, :3] - m["T"][k][:3, :3]).max() > TOL_ROT
+        close_to_reference(poses[k], o.T)
+    assert sensitive <= 1
+    assert int(np.argmin(errors)) == int(m["best"])
+    close_to_reference(pose, m["best_pose"])
+    assert isinstance(err, np.float64) and abs(err - m["best_error"]) < 2e-5 * m["best_error"]
+    np.testing.assert_allclose(W.yaw_starts(g["src"], g["tgt"])[[0, 4, 5, 13]], g["init"], atol=1e-12)
+
+
 def test_get_transform_get_error_get_correspondences(icp):
     from oracle import c_oracle
     g = golden("kabsch.npz")

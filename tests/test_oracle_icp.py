@@ -57,6 +57,23 @@ def test_3d_multistart(nn):
         _check(r, g["T"][k], g["error"][k], g["corr"][k], g["iterations"][k])
 
 
+def test_24_yaw_multistart_best_of():
+    """the registration loop of code/icp_warm_up/test_icp.py:66-92 restated with the oracle"""
+    g, m = golden("icp_3d.npz"), golden("icp_multistart.npz")
+    src, tgt = g["src"], g["tgt"]
+    errs = []
+    for k, yaw in enumerate(np.linspace(0, 2 * np.pi, 24, endpoint=False)):
+        T0 = np.eye(4)
+        T0[:3, :3] = [[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]]
+        T0[:3, 3] = tgt.mean(0) - T0[:3, :3] @ src.mean(0)
+        r = O.run_icp_full(src, tgt, T0, epsilon=0.001, normalize_error=True)
+        np.testing.assert_allclose(r.T, m["T"][k], atol=1e-9)
+        assert r.iterations == m["iterations"][k]
+        errs.append(r.error)
+    np.testing.assert_allclose(errs, m["error"], rtol=1e-9)
+    assert int(np.argmin(errs)) == int(m["best"])
+
+
 def test_kabsch_cases_svd_and_closed_forms():
     g = golden("kabsch.npz")
     ps, qs = split(g["p"], g["off"]), split(g["q"], g["off"])
