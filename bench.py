@@ -329,7 +329,7 @@ def other_config(name, a, torch, device, stream, timed):
         return {"workload": "OGM build_map: 4956 scans of the C3 sequence into a 1201x1201 grid (res 0.05), host arrays in (PCIe included)",
                 "seconds": dt, "scans_per_sec": len(seq.z_ts) / dt, "rays_per_sec": rays / dt,
                 "cell_updates_per_sec": cells / k * len(seq.z_ts) / dt, "cell_updates_per_scan": cells / k,
-                "roofline_note": "ray kernel: scattered int32 atomics (L2-atomic bound, ~40 G/s measured); apply kernel: HBM streaming of 32 count planes over the touched box; see DESIGN.md 3.4 and profiles/r01/bench_default_kernel_stats_lslam.csv",
+                "roofline_note": "no scattered HBM access: ray records -> per-(scan, 64x64 tile) LDS accumulation -> coalesced int16 count planes -> per-cell apply in scan order; tile kernel bound by the LDS walk, apply kernel by its float64 update chain; see DESIGN.md 3.4 and profiles/r01/bench_default_kernel_stats.csv",
                 "cpu_port_seconds_per_scan": cpu_s, "cpu_port_extrapolated_seconds": cpu_s * len(seq.z_ts),
                 "speedup_vs_cpu_port_1core": cpu_s * len(seq.z_ts) / dt,
                 "logodds_equal_to_oracle_on_sample": bool(np.array_equal(g2.grid_map_log_odds, o.grid_map_log_odds))}

@@ -714,9 +714,11 @@ struct ScanSet {
 struct Ogm {
   OgmGrid g{};
   int device = 0;
-  int parity = 0;
   hipStream_t stream = nullptr;
   double* d_scan = nullptr; int64_t scan_cap = 0;     // points
+  int4* d_rays = nullptr; int64_t rays_cap = 0;       // one record per ray of the current call
+  int4* d_batch = nullptr;                            // one box per 64 rays of a scan (rays_cap / 64 + desc_cap of them)
+  int* d_boxes = nullptr; int64_t boxes_cap = 0;      // one touched box per scan of the current call
   uint8_t* d_bin = nullptr;
   OgmScan* d_desc = nullptr; int64_t desc_cap = 0;    // one descriptor per scan of the current call
   std::vector<OgmScan> h_desc;
@@ -860,8 +862,6 @@ int lslam_ogm_create(double res, double world_min_x, double world_min_y, int32_t
   if ((e = hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipMalloc(&o->g.logodds, sizeof(float) * cells)) != hipSuccess ||
       (e = hipMalloc(&o->g.counts, sizeof(int32_t) * cells * kOgmPlanes)) != hipSuccess ||
-      (e = hipMalloc(&o->g.bbox, sizeof(int32_t) * 8 * kOgmPlanes)) != hipSuccess ||
-
       (e = hipMalloc(&o->d_bin, cells)) != hipSuccess ||
       (e = launch_ogm_init(o->g, o->stream)) != hipSuccess ||
       (e = hipStreamSynchronize(o->stream)) != hipSuccess) {
@@ -879,7 +879,9 @@ int lslam_ogm_destroy(void* handle) {
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   if (o->g.logodds) (void)hipFree(o->g.logodds);
   if (o->g.counts) (void)hipFree(o->g.counts);
-  if (o->g.bbox) (void)hipFree(o->g.bbox);
+  if (o->d_rays) (void)hipFree(o->d_rays);
+  if (o->d_batch) (void)hipFree(o->d_batch);
+  if (o->d_boxes) (void)hipFree(o->d_boxes);
   if (o->d_scan) (void)hipFree(o->d_scan);
   if (o->d_bin) (void)hipFree(o->d_bin);
   if (o->d_desc) (void)hipFree(o->d_desc);
@@ -897,34 +899,46 @@ int lslam_ogm_set_params(void* handle, double logodds_step, double logodds_clip)
   return LSLAM_OK;
 }
 
-// Upload one descriptor per scan, then per group of up to kOgmPlanes scans: raycast launch → apply
-// (or nothing) launch.  No host synchronisation inside.
+// Upload one descriptor per scan; one launch turns every ray into a record and every scan into a touched
+// box; then per group of up to kOgmPlanes scans: tile launch → apply (or nothing) launch.  No host
+// synchronisation inside.
 static int ogm_enqueue(Ogm* o, const double* poses, const double* d_points, const int64_t* scan_off,
                        int64_t first_point, int32_t K, bool apply) {
-  if (K > o->desc_cap) {
+  if (K <= 0) return LSLAM_OK;
+  const int64_t total = scan_off[K] - first_point;
+  if (K > o->desc_cap || total > o->rays_cap) {
     if (o->d_desc) (void)hipFree(o->d_desc);
-    o->d_desc = nullptr; o->desc_cap = 0;
-    const int64_t want = K + K / 4 + 64;
-    LSLAM_HIP_TRY(hipMalloc(&o->d_desc, sizeof(OgmScan) * (size_t)want));
-    o->desc_cap = want;
+    if (o->d_boxes) (void)hipFree(o->d_boxes);
+    if (o->d_rays) (void)hipFree(o->d_rays);
+    if (o->d_batch) (void)hipFree(o->d_batch);
+    o->d_desc = nullptr; o->d_boxes = nullptr; o->d_rays = nullptr; o->d_batch = nullptr; o->desc_cap = 0; o->rays_cap = 0;
+    const int64_t want_k = K + K / 4 + 64, want_r = total + total / 4 + 1024;
+    LSLAM_HIP_TRY(hipMalloc(&o->d_desc, sizeof(OgmScan) * (size_t)want_k));
+    LSLAM_HIP_TRY(hipMalloc(&o->d_boxes, sizeof(int) * 4 * (size_t)want_k));
+    LSLAM_HIP_TRY(hipMalloc(&o->d_rays, sizeof(int4) * (size_t)want_r));
+    LSLAM_HIP_TRY(hipMalloc(&o->d_batch, sizeof(int4) * (size_t)(want_r / 64 + want_k + 1)));
+    o->desc_cap = want_k; o->rays_cap = want_r;
   }
   o->h_desc.resize((size_t)K);
+  int max_rays = 0;
   for (int32_t k = 0; k < K; ++k) {
     const double* pose = poses + 3 * (size_t)k;
     OgmScan& h = o->h_desc[(size_t)k];
-    h.scan_xy = d_points + 2 * (scan_off[k] - first_point);
+    h.ray_base = scan_off[k] - first_point;
+    h.batch_base = h.ray_base / 64 + k;                      // distinct slots: scan k+1 starts past the last batch of scan k
+    h.scan_xy = d_points + 2 * h.ray_base;
     h.n = (int32_t)(scan_off[k + 1] - scan_off[k]);
     h.x = pose[0]; h.y = pose[1]; h.c = cos(pose[2]); h.s = sin(pose[2]);
     h.pad_ = 0;
+    if (h.n > max_rays) max_rays = h.n;
   }
-  if (K > 0) LSLAM_HIP_TRY(hipMemcpyAsync(o->d_desc, o->h_desc.data(), sizeof(OgmScan) * (size_t)K, hipMemcpyHostToDevice, o->stream));
+  LSLAM_HIP_TRY(hipMemcpyAsync(o->d_desc, o->h_desc.data(), sizeof(OgmScan) * (size_t)K, hipMemcpyHostToDevice, o->stream));
+  const bool wide = max_rays > 32767;
+  LSLAM_HIP_TRY(launch_ogm_rays(o->g, o->d_desc, K, max_rays, o->d_rays, o->d_boxes, o->d_batch, o->stream));
   for (int32_t k0 = 0; k0 < K; k0 += kOgmPlanes) {
     const int32_t cnt = (K - k0 < kOgmPlanes) ? (K - k0) : kOgmPlanes;
-    int max_rays = 0;
-    for (int32_t b = 0; b < cnt; ++b) if (o->h_desc[(size_t)(k0 + b)].n > max_rays) max_rays = o->h_desc[(size_t)(k0 + b)].n;
-    LSLAM_HIP_TRY(launch_ogm_raycast(o->g, o->d_desc + k0, cnt, max_rays, o->parity, o->stream));
-    if (apply) LSLAM_HIP_TRY(launch_ogm_apply(o->g, cnt, o->parity, 0, o->stream));
-    o->parity ^= 1;
+    LSLAM_HIP_TRY(launch_ogm_tiles(o->g, o->d_desc + k0, cnt, o->d_rays, o->d_boxes + 4 * (size_t)k0, o->d_batch, wide, o->stream));
+    if (apply) LSLAM_HIP_TRY(launch_ogm_apply(o->g, o->d_boxes + 4 * (size_t)k0, cnt, wide, o->stream));
   }
   return LSLAM_OK;
 }
@@ -973,12 +987,21 @@ int lslam_ogm_scan_counts(void* handle, const double* pose, const double* scan_x
   int rc;
   if ((rc = ogm_scan_buffer(o, n)) != LSLAM_OK) return rc;
   if (n > 0) LSLAM_HIP_TRY(hipMemcpyAsync(o->d_scan, scan_xy, sizeof(double) * 2 * (size_t)n, hipMemcpyHostToDevice, o->stream));
-  const int parity = o->parity;
   const int64_t off[2] = {0, n};
+  const size_t cells = (size_t)o->g.width * o->g.height;
+  const bool wide = n > 32767;                              // as ogm_enqueue decides
+  // plane 0 is written inside the scan's box only; the caller gets the whole grid
+  LSLAM_HIP_TRY(hipMemsetAsync(o->g.counts, 0, sizeof(int32_t) * cells, o->stream));
   if ((rc = ogm_enqueue(o, pose, o->d_scan, off, 0, 1, false)) != LSLAM_OK) return rc;
-  LSLAM_HIP_TRY(hipMemcpyAsync(out_counts, o->g.counts, sizeof(int32_t) * (size_t)o->g.width * o->g.height, hipMemcpyDeviceToHost, o->stream));
-  LSLAM_HIP_TRY(launch_ogm_apply(o->g, 1, parity, 1, o->stream));      // clear only
-  LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+  if (wide) {
+    LSLAM_HIP_TRY(hipMemcpyAsync(out_counts, o->g.counts, sizeof(int32_t) * cells, hipMemcpyDeviceToHost, o->stream));
+    LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+  } else {
+    std::vector<int16_t> narrow(cells);
+    LSLAM_HIP_TRY(hipMemcpyAsync(narrow.data(), o->g.counts, sizeof(int16_t) * cells, hipMemcpyDeviceToHost, o->stream));
+    LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+    for (size_t i = 0; i < cells; ++i) out_counts[i] = narrow[i];
+  }
   return LSLAM_OK;
 }
 

@@ -193,12 +193,11 @@ hipError_t launch_pair_op(const PairOpArgs& a, hipStream_t stream);
 hipError_t run_valu_probe(float* d_scratch, hipStream_t stream, double* lane_ops_per_s);
 
 // ---- occupancy grid (lslam_ogm.hip) -----------------------------------------------------------------
-constexpr int kOgmPlanes = 32;   // scans traced per launch, each into its own int32 count plane
+constexpr int kOgmPlanes = 128;  // scans per tile/apply launch pair, each with its own int32 count plane
 
 struct OgmGrid {
   float* logodds;          // width*height, [x][y]
-  int32_t* counts;         // kOgmPlanes planes of width*height hit-miss counts, zero between groups
-  int32_t* bbox;           // 2 parities x kOgmPlanes x {min_x, min_y, max_x, max_y}
+  int32_t* counts;         // kOgmPlanes planes of width*height hit-miss counts (int16, or int32 for scans above 32767 rays); a plane is valid inside its scan's box only
   int32_t width, height;
   double res, min_x, min_y;
   double step, clip;
@@ -206,11 +205,18 @@ struct OgmGrid {
 struct OgmScan {
   const double* scan_xy;   // device, n x 2
   double x, y, c, s;       // pose, cos/sin of yaw
+  int64_t ray_base;        // first ray record of this scan
+  int64_t batch_base;      // first 64-ray batch box of this scan
   int32_t n;
   int32_t pad_;
 };
-hipError_t launch_ogm_raycast(const OgmGrid& g, const OgmScan* d_scans, int nscans, int max_rays, int parity, hipStream_t stream);
-hipError_t launch_ogm_apply(const OgmGrid& g, int nscans, int parity, int clear_only, hipStream_t stream);
+// d_rays: one int4 {end_x, end_y, k_first, k_last} per ray; d_boxes: {min_x, min_y, −max_x, −max_y} per scan;
+// d_batch_boxes: the same per 64 consecutive rays of a scan.  `wide`: int32 count planes (a scan above 32767 rays), else int16.
+hipError_t launch_ogm_rays(const OgmGrid& g, const OgmScan* d_scans, int nscans, int max_rays, int4* d_rays, int* d_boxes, int4* d_batch_boxes,
+                           hipStream_t stream);
+hipError_t launch_ogm_tiles(const OgmGrid& g, const OgmScan* d_scans, int nscans, const int4* d_rays, const int* d_boxes,
+                            const int4* d_batch_boxes, bool wide, hipStream_t stream);
+hipError_t launch_ogm_apply(const OgmGrid& g, const int* d_boxes, int nscans, bool wide, hipStream_t stream);
 hipError_t launch_ogm_binarize(const OgmGrid& g, uint8_t* out, hipStream_t stream);
 hipError_t launch_ogm_init(const OgmGrid& g, hipStream_t stream);
 

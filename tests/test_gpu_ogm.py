@@ -86,3 +86,50 @@ def test_sequence_order_and_clip_random_scans():
     assert np.abs(orc.grid_map_log_odds).max() == 20.0
     np.testing.assert_array_equal(grid.grid_map_log_odds, orc.grid_map_log_odds)
     np.testing.assert_array_equal(grid.grid_map, orc.grid_map)
+
+
+def test_many_groups_unsorted_rays_far_ends_and_empty_scans():
+    """more scans than one launch group holds, rays in random angular order, scans without rays, poses off the
+    map, beam ends tens of thousands of cells away (the 64-bit division path), a map that is not a whole
+    number of tiles"""
+    from lidar_slam_amd.modules.ogm import OccupancyGridMap
+    from oracle.ogm_oracle import OccupancyGridOracle
+    rng = np.random.default_rng(5)
+    grid = OccupancyGridMap(0.1, 10, 10, -10, -10)
+    orc = OccupancyGridOracle(0.1, 10, 10, -10, -10)
+    poses, scans = [], []
+    for k in range(300):
+        off_map = k % 37 == 0
+        poses.append([rng.uniform(12, 15) if off_map else rng.uniform(-6, 6), rng.uniform(-6, 6), rng.uniform(-3, 3)])
+        n = 0 if k % 41 == 0 else int(rng.integers(1, 160))
+        a = rng.uniform(-np.pi, np.pi, n)
+        r = rng.uniform(0.2, 25, n)
+        r[rng.random(n) < 0.03] = 6000.0                     # ≥ 46340 cells: multiply-high division does not apply
+        scans.append(np.column_stack((r * np.cos(a), r * np.sin(a))))
+    grid.build_map(np.array(poses), scans)
+    orc.build_map(np.array(poses), scans)
+    np.testing.assert_array_equal(grid.grid_map_log_odds, orc.grid_map_log_odds)
+    np.testing.assert_array_equal(grid.grid_map, orc.grid_map)
+    # the per-scan count grid of a scan whose box is a sliver of the map: everything else must read as zero
+    cnt = grid.scan_counts(np.array([0.0, 0.0, 0.0]), np.array([[3.0, 0.0]]))
+    ref = orc.scan_counts(np.array([0.0, 0.0, 0.0]), np.array([[3.0, 0.0]]))
+    np.testing.assert_array_equal(cnt, ref)
+
+
+def test_scan_with_more_rays_than_int16_counts_hold():
+    """above 32767 rays per scan the count planes are int32 (a cell next to the sensor is crossed by every ray)"""
+    from lidar_slam_amd.modules.ogm import OccupancyGridMap
+    from oracle.ogm_oracle import OccupancyGridOracle
+    rng = np.random.default_rng(6)
+    n = 40000
+    a = rng.uniform(-0.2, 0.2, n); r = rng.uniform(3, 8, n)
+    scan = np.column_stack((r * np.cos(a), r * np.sin(a)))
+    pose = np.array([0.3, -0.2, 0.5])
+    grid = OccupancyGridMap(0.1, 10, 10, -10, -10)
+    orc = OccupancyGridOracle(0.1, 10, 10, -10, -10)
+    ref = orc.scan_counts(pose, scan)
+    assert ref.min() < -32768
+    np.testing.assert_array_equal(grid.scan_counts(pose, scan), ref)
+    grid.update_map(pose, scan)
+    orc.apply_counts(ref)
+    np.testing.assert_array_equal(grid.grid_map_log_odds, orc.grid_map_log_odds)
