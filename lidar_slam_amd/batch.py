@@ -39,7 +39,9 @@ def pack_clouds(clouds):
         raise ValueError("all clouds of a batch must be (n_i, d) with the same d")
     if not len(clouds):
         return np.zeros((0, d), np.float32), off
-    return np.ascontiguousarray(np.concatenate(clouds, axis=0).astype(np.float32)), off
+    flat = np.empty((int(off[-1]), d), dtype=np.float32)
+    np.concatenate(clouds, axis=0, out=flat, casting="same_kind")      # one pass: gather and round to float32
+    return flat, off
 
 
 def icp_batch(src, src_off, tgt, tgt_off, init_T, epsilon=0.01, max_iters=2000, stopping_thresh=0.0001,

@@ -718,10 +718,12 @@ struct Ogm {
   double* d_scan = nullptr; int64_t scan_cap = 0;     // points
   int4* d_rays = nullptr; int64_t rays_cap = 0;       // one record per ray of the current call
   int4* d_batch = nullptr;                            // one box per 64 rays of a scan (rays_cap / 64 + desc_cap of them)
+  int planes_cap = 0;                                 // count planes allocated so far (grows to kOgmPlanes on the first long call)
   int* d_boxes = nullptr; int64_t boxes_cap = 0;      // one touched box per scan of the current call
   uint8_t* d_bin = nullptr;
   OgmScan* d_desc = nullptr; int64_t desc_cap = 0;    // one descriptor per scan of the current call
   std::vector<OgmScan> h_desc;
+  std::vector<int> h_boxes;                           // host copy of the touched boxes: sizes the launches
 };
 int ogm_scan_buffer(Ogm* o, int64_t points) {
   if (points <= o->scan_cap) return LSLAM_OK;
@@ -861,7 +863,6 @@ int lslam_ogm_create(double res, double world_min_x, double world_min_y, int32_t
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipMalloc(&o->g.logodds, sizeof(float) * cells)) != hipSuccess ||
-      (e = hipMalloc(&o->g.counts, sizeof(int32_t) * cells * kOgmPlanes)) != hipSuccess ||
       (e = hipMalloc(&o->d_bin, cells)) != hipSuccess ||
       (e = launch_ogm_init(o->g, o->stream)) != hipSuccess ||
       (e = hipStreamSynchronize(o->stream)) != hipSuccess) {
@@ -899,6 +900,16 @@ int lslam_ogm_set_params(void* handle, double logodds_step, double logodds_clip)
   return LSLAM_OK;
 }
 
+static int ogm_planes(Ogm* o, int planes) {
+  if (planes <= o->planes_cap) return LSLAM_OK;
+  LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+  if (o->g.counts) (void)hipFree(o->g.counts);
+  o->g.counts = nullptr; o->planes_cap = 0;
+  LSLAM_HIP_TRY(hipMalloc(&o->g.counts, sizeof(int32_t) * (size_t)o->g.width * o->g.height * (size_t)planes));
+  o->planes_cap = planes;
+  return LSLAM_OK;
+}
+
 // Upload one descriptor per scan; one launch turns every ray into a record and every scan into a touched
 // box; then per group of up to kOgmPlanes scans: tile launch → apply (or nothing) launch.  No host
 // synchronisation inside.
@@ -906,6 +917,8 @@ static int ogm_enqueue(Ogm* o, const double* poses, const double* d_points, cons
                        int64_t first_point, int32_t K, bool apply) {
   if (K <= 0) return LSLAM_OK;
   const int64_t total = scan_off[K] - first_point;
+  int rc_planes = ogm_planes(o, K < kOgmPlanes ? K : kOgmPlanes);     // update_map needs one plane, build_map a full group
+  if (rc_planes != LSLAM_OK) return rc_planes;
   if (K > o->desc_cap || total > o->rays_cap) {
     if (o->d_desc) (void)hipFree(o->d_desc);
     if (o->d_boxes) (void)hipFree(o->d_boxes);
@@ -935,10 +948,24 @@ static int ogm_enqueue(Ogm* o, const double* poses, const double* d_points, cons
   LSLAM_HIP_TRY(hipMemcpyAsync(o->d_desc, o->h_desc.data(), sizeof(OgmScan) * (size_t)K, hipMemcpyHostToDevice, o->stream));
   const bool wide = max_rays > 32767;
   LSLAM_HIP_TRY(launch_ogm_rays(o->g, o->d_desc, K, max_rays, o->d_rays, o->d_boxes, o->d_batch, o->stream));
+  // the boxes come back (16 bytes per scan) so that the launches below cover exactly the touched tiles and cells
+  o->h_boxes.resize(4 * (size_t)K);
+  LSLAM_HIP_TRY(hipMemcpyAsync(o->h_boxes.data(), o->d_boxes, sizeof(int) * 4 * (size_t)K, hipMemcpyDeviceToHost, o->stream));
+  LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
   for (int32_t k0 = 0; k0 < K; k0 += kOgmPlanes) {
     const int32_t cnt = (K - k0 < kOgmPlanes) ? (K - k0) : kOgmPlanes;
-    LSLAM_HIP_TRY(launch_ogm_tiles(o->g, o->d_desc + k0, cnt, o->d_rays, o->d_boxes + 4 * (size_t)k0, o->d_batch, wide, o->stream));
-    if (apply) LSLAM_HIP_TRY(launch_ogm_apply(o->g, o->d_boxes + 4 * (size_t)k0, cnt, wide, o->stream));
+    int tiles_x = 0, tiles_y = 0, x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
+    for (int32_t b = 0; b < cnt; ++b) {
+      const int* box = o->h_boxes.data() + 4 * (size_t)(k0 + b);
+      if (box[0] == kOgmBoxEmpty) continue;
+      int tx, ty;
+      ogm_tile_span(box, &tx, &ty);
+      tiles_x = tx > tiles_x ? tx : tiles_x; tiles_y = ty > tiles_y ? ty : tiles_y;
+      x0 = box[0] < x0 ? box[0] : x0; y0 = box[1] < y0 ? box[1] : y0;
+      x1 = -box[2] > x1 ? -box[2] : x1; y1 = -box[3] > y1 ? -box[3] : y1;
+    }
+    LSLAM_HIP_TRY(launch_ogm_tiles(o->g, o->d_desc + k0, cnt, o->d_rays, o->d_boxes + 4 * (size_t)k0, o->d_batch, wide, tiles_x, tiles_y, o->stream));
+    if (apply) LSLAM_HIP_TRY(launch_ogm_apply(o->g, o->d_boxes + 4 * (size_t)k0, cnt, wide, x0, y0, x1, y1, o->stream));
   }
   return LSLAM_OK;
 }
@@ -991,6 +1018,7 @@ int lslam_ogm_scan_counts(void* handle, const double* pose, const double* scan_x
   const size_t cells = (size_t)o->g.width * o->g.height;
   const bool wide = n > 32767;                              // as ogm_enqueue decides
   // plane 0 is written inside the scan's box only; the caller gets the whole grid
+  if ((rc = ogm_planes(o, 1)) != LSLAM_OK) return rc;
   LSLAM_HIP_TRY(hipMemsetAsync(o->g.counts, 0, sizeof(int32_t) * cells, o->stream));
   if ((rc = ogm_enqueue(o, pose, o->d_scan, off, 0, 1, false)) != LSLAM_OK) return rc;
   if (wide) {

@@ -214,9 +214,13 @@ struct OgmScan {
 // d_batch_boxes: the same per 64 consecutive rays of a scan.  `wide`: int32 count planes (a scan above 32767 rays), else int16.
 hipError_t launch_ogm_rays(const OgmGrid& g, const OgmScan* d_scans, int nscans, int max_rays, int4* d_rays, int* d_boxes, int4* d_batch_boxes,
                            hipStream_t stream);
+// tiles_x / tiles_y: the largest number of map tiles a box of the group spans per axis (ogm_tile_span on the host copy of the boxes)
 hipError_t launch_ogm_tiles(const OgmGrid& g, const OgmScan* d_scans, int nscans, const int4* d_rays, const int* d_boxes,
-                            const int4* d_batch_boxes, bool wide, hipStream_t stream);
-hipError_t launch_ogm_apply(const OgmGrid& g, const int* d_boxes, int nscans, bool wide, hipStream_t stream);
+                            const int4* d_batch_boxes, bool wide, int tiles_x, int tiles_y, hipStream_t stream);
+// (x0, y0, x1, y1): union of the group's boxes
+hipError_t launch_ogm_apply(const OgmGrid& g, const int* d_boxes, int nscans, bool wide, int x0, int y0, int x1, int y1, hipStream_t stream);
+void ogm_tile_span(const int* box, int* tiles_x, int* tiles_y);
+constexpr int kOgmBoxEmpty = 0x7f7f7f7f;
 hipError_t launch_ogm_binarize(const OgmGrid& g, uint8_t* out, hipStream_t stream);
 hipError_t launch_ogm_init(const OgmGrid& g, hipStream_t stream);
 

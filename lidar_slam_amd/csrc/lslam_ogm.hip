@@ -34,7 +34,7 @@ constexpr int kTile = 64;                 // map tile (cells per side) accumulat
 constexpr int kTilePitch = kTile + 1;     // odd: the 64 cells a wave adds to along an x-major ray sit in 64 banks
 constexpr int kTileThreads = 256;
 static_assert(kOgmPlanes <= 128, "the apply kernel stages the boxes of a group in two registers per lane");
-constexpr int kBoxEmpty = 0x7f7f7f7f;     // boxes are {min_x, min_y, −max_x, −max_y}, all reduced with atomicMin, memset(0x7f) = empty
+constexpr int kBoxEmpty = kOgmBoxEmpty;     // boxes are {min_x, min_y, −max_x, −max_y}, all reduced with atomicMin, memset(0x7f) = empty
 
 __device__ __forceinline__ int world2grid(double v, double vmin, double res) {
   return (int)ceil((v - vmin) / res) - 1;                 // ogm.py:117-118
@@ -164,7 +164,8 @@ ogm_tile_kernel(OgmGrid g, const OgmScan* __restrict__ scans, const int4* __rest
   const int* bb = boxes + 4 * (int64_t)b;
   const int box_x0 = bb[0], box_y0 = bb[1], box_x1 = -bb[2], box_y1 = -bb[3];
   if (box_x0 == kBoxEmpty) return;
-  const int tx0 = blockIdx.y * kTile, ty0 = blockIdx.x * kTile;          // x is the slow axis of the grid arrays
+  // tiles are those of the map grid, counted from the first one the scan's box meets (x is the slow axis of the arrays)
+  const int tx0 = (box_x0 / kTile + blockIdx.y) * kTile, ty0 = (box_y0 / kTile + blockIdx.x) * kTile;
   const int tx1 = tx0 + kTile - 1, ty1 = ty0 + kTile - 1;
   if (tx0 > box_x1 || tx1 < box_x0 || ty0 > box_y1 || ty1 < box_y0) return;
   const OgmScan sc = scans[b];
@@ -222,61 +223,63 @@ ogm_tile_kernel(OgmGrid g, const OgmScan* __restrict__ scans, const int4* __rest
       plane[(int64_t)cx * g.height + cy] = (CT)tile[(cx - tx0) * kTilePitch + lane];
 }
 
-// One thread per cell; planes visited in scan order, each only inside its scan's box.
-// A wave covers 64 consecutive y at one x, so "does this plane's box meet my cells" is decided per wave
+// Two cells (64 apart in y) per thread; planes visited in scan order, each only inside its scan's box.
+// A wave covers 128 consecutive y at one x, so "does this plane's box meet my cells" is decided per wave
 // on scalars (boxes are staged in two registers per lane and broadcast with readlane); lanes outside the
 // box in y drop the value they loaded.  All loads of a chunk of planes are issued before the first use.
+// (x0, y0, x1, y1) is the union of the group's boxes, computed by the host, which sizes the grid to it.
 template <typename CT>
 __global__ void __launch_bounds__(256)
-ogm_apply_kernel(OgmGrid g, const int* __restrict__ boxes, int nplanes) {
+ogm_apply_kernel(OgmGrid g, const int* __restrict__ boxes, int nplanes, int x0, int y0, int x1, int y1) {
   const int lane = threadIdx.x & 63;
   const CT* __restrict__ counts = reinterpret_cast<const CT*>(g.counts);
   const int4* boxes4 = reinterpret_cast<const int4*>(boxes);
   const int4 none = make_int4(kBoxEmpty, kBoxEmpty, kBoxEmpty, kBoxEmpty);
   const int4 boxA = lane < nplanes ? boxes4[lane] : none;
   const int4 boxB = 64 + lane < nplanes ? boxes4[64 + lane] : none;
-  // union of the touched boxes ({min, min, −max, −max}: all four reduce with min; an empty box is neutral)
-  const int x0 = wave_min_i(min(boxA.x, boxB.x)), y0 = wave_min_i(min(boxA.y, boxB.y));
-  const int x1 = -wave_min_i(min(boxA.z, boxB.z)), y1 = -wave_min_i(min(boxA.w, boxB.w));
-  if (x0 == kBoxEmpty) return;
-  // one cell per thread: blockIdx.x tiles y (contiguous in memory) by 64, blockIdx.y tiles x by 4
-  const int wy0 = y0 + blockIdx.x * 64;
+  const int wy0 = y0 + blockIdx.x * 128;
   const int cx = __builtin_amdgcn_readfirstlane(x0 + blockIdx.y * 4 + (threadIdx.x >> 6));
   if (wy0 > y1 || cx > x1) return;                          // whole wave
-  const int wy1 = min(wy0 + 63, y1);
-  const bool live = wy0 + lane <= y1;
-  const int cy = min(wy0 + lane, y1);                       // idle lanes shadow the last live one (in-bounds loads, no store)
+  const int wy1 = min(wy0 + 127, y1);
+  const bool live0 = wy0 + lane <= y1, live1 = wy0 + 64 + lane <= y1;
+  const int cy0 = min(wy0 + lane, y1), cy1 = min(wy0 + 64 + lane, y1);   // idle lanes shadow the last live one (in-bounds loads, no store)
   const int64_t stride = (int64_t)g.width * g.height;
-  const int64_t idx = (int64_t)cx * g.height + cy;
-  constexpr int kChunk = 32;
-  float l = g.logodds[idx];
-  bool dirty = false;
+  const int64_t idx0 = (int64_t)cx * g.height + cy0, idx1 = (int64_t)cx * g.height + cy1;
+  constexpr int kChunk = 16;
+  float l0 = g.logodds[idx0], l1 = g.logodds[idx1];
+  bool dirty0 = false, dirty1 = false;
+  const double step = g.step, clip = g.clip;
   for (int b0 = 0; b0 < nplanes; b0 += kChunk) {
     const bool second = b0 >= 64;
     const int4 bx = second ? boxB : boxA;
-    int c[kChunk];
+    int c0[kChunk], c1[kChunk];
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {
       const int src = (b0 & 63) + j;
       const int px0 = __builtin_amdgcn_readlane(bx.x, src), py0 = __builtin_amdgcn_readlane(bx.y, src);
       const int px1 = -__builtin_amdgcn_readlane(bx.z, src), py1 = -__builtin_amdgcn_readlane(bx.w, src);
-      c[j] = 0;
+      c0[j] = 0; c1[j] = 0;
       if (cx >= px0 && cx <= px1 && wy0 <= py1 && wy1 >= py0) {      // scalar; an empty box fails cx >= px0
-        const int v = counts[(int64_t)(b0 + j) * stride + idx];
-        c[j] = (cy >= py0 && cy <= py1) ? v : 0;
+        const CT* pl = counts + (int64_t)(b0 + j) * stride;
+        const int v0 = pl[idx0], v1 = pl[idx1];
+        c0[j] = (cy0 >= py0 && cy0 <= py1) ? v0 : 0;
+        c1[j] = (cy1 >= py0 && cy1 <= py1) ? v1 : 0;
       }
     }
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {
-      if (c[j] != 0) {
-        double v = (double)l + (double)c[j] * g.step;
-        v = fmin(fmax(v, -g.clip), g.clip);
-        l = (float)v;
-        dirty = true;
+      if (c0[j] != 0) {
+        l0 = (float)fmin(fmax((double)l0 + (double)c0[j] * step, -clip), clip);
+        dirty0 = true;
+      }
+      if (c1[j] != 0) {
+        l1 = (float)fmin(fmax((double)l1 + (double)c1[j] * step, -clip), clip);
+        dirty1 = true;
       }
     }
   }
-  if (dirty && live) g.logodds[idx] = l;
+  if (dirty0 && live0) g.logodds[idx0] = l0;
+  if (dirty1 && live1) g.logodds[idx1] = l1;
 }
 
 __global__ void ogm_binarize_kernel(OgmGrid g, uint8_t* out) {
@@ -307,19 +310,25 @@ hipError_t launch_ogm_rays(const OgmGrid& g, const OgmScan* d_scans, int nscans,
 // scans [0, nscans) of the group go to planes 0 … nscans−1 (nscans ≤ kOgmPlanes).  The count of a cell is at most
 // the number of rays of the scan in magnitude: int16 planes unless a scan has more than 32767 rays.
 hipError_t launch_ogm_tiles(const OgmGrid& g, const OgmScan* d_scans, int nscans, const int4* d_rays, const int* d_boxes,
-                            const int4* d_batch_boxes, bool wide, hipStream_t stream) {
-  if (nscans <= 0) return hipSuccess;
-  const dim3 grid((g.height + kTile - 1) / kTile, (g.width + kTile - 1) / kTile, nscans);
+                            const int4* d_batch_boxes, bool wide, int tiles_x, int tiles_y, hipStream_t stream) {
+  if (nscans <= 0 || tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
+  const dim3 grid(tiles_y, tiles_x, nscans);
   if (wide) hipLaunchKernelGGL(ogm_tile_kernel<int32_t>, grid, dim3(kTileThreads), 0, stream, g, d_scans, d_rays, d_boxes, d_batch_boxes);
   else hipLaunchKernelGGL(ogm_tile_kernel<int16_t>, grid, dim3(kTileThreads), 0, stream, g, d_scans, d_rays, d_boxes, d_batch_boxes);
   return hipGetLastError();
 }
-hipError_t launch_ogm_apply(const OgmGrid& g, const int* d_boxes, int nscans, bool wide, hipStream_t stream) {
-  if (nscans <= 0) return hipSuccess;
-  const dim3 grid((g.height + 63) / 64, (g.width + 3) / 4);
-  if (wide) hipLaunchKernelGGL(ogm_apply_kernel<int32_t>, grid, dim3(256), 0, stream, g, d_boxes, nscans);
-  else hipLaunchKernelGGL(ogm_apply_kernel<int16_t>, grid, dim3(256), 0, stream, g, d_boxes, nscans);
+hipError_t launch_ogm_apply(const OgmGrid& g, const int* d_boxes, int nscans, bool wide, int x0, int y0, int x1, int y1, hipStream_t stream) {
+  if (nscans <= 0 || x1 < x0 || y1 < y0) return hipSuccess;
+  const dim3 grid((y1 - y0) / 128 + 1, (x1 - x0) / 4 + 1);
+  if (wide) hipLaunchKernelGGL(ogm_apply_kernel<int32_t>, grid, dim3(256), 0, stream, g, d_boxes, nscans, x0, y0, x1, y1);
+  else hipLaunchKernelGGL(ogm_apply_kernel<int16_t>, grid, dim3(256), 0, stream, g, d_boxes, nscans, x0, y0, x1, y1);
   return hipGetLastError();
+}
+// how many map tiles a box spans per axis (the tile kernel counts tiles from the first one the box meets)
+void ogm_tile_span(const int* box, int* tiles_x, int* tiles_y) {
+  if (box[0] == kBoxEmpty) { *tiles_x = *tiles_y = 0; return; }
+  *tiles_x = (-box[2]) / kTile - box[0] / kTile + 1;
+  *tiles_y = (-box[3]) / kTile - box[1] / kTile + 1;
 }
 hipError_t launch_ogm_binarize(const OgmGrid& g, uint8_t* out, hipStream_t stream) {
   const int64_t n = (int64_t)g.width * g.height;
