@@ -721,6 +721,7 @@ struct Ogm {
   int planes_cap = 0;                                 // count planes allocated so far (grows to kOgmPlanes on the first long call)
   int* d_boxes = nullptr; int64_t boxes_cap = 0;      // one touched box per scan of the current call
   uint8_t* d_bin = nullptr;
+  float* d_values = nullptr;                          // read-out staging: f32(base + steps·step)
   OgmScan* d_desc = nullptr; int64_t desc_cap = 0;    // one descriptor per scan of the current call
   std::vector<OgmScan> h_desc;
   std::vector<int> h_boxes;                           // host copy of the touched boxes: sizes the launches
@@ -863,6 +864,8 @@ int lslam_ogm_create(double res, double world_min_x, double world_min_y, int32_t
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipMalloc(&o->g.logodds, sizeof(float) * cells)) != hipSuccess ||
+      (e = hipMalloc(&o->g.steps, sizeof(int32_t) * cells)) != hipSuccess ||
+      (e = hipMalloc(&o->d_values, sizeof(float) * cells)) != hipSuccess ||
       (e = hipMalloc(&o->d_bin, cells)) != hipSuccess ||
       (e = launch_ogm_init(o->g, o->stream)) != hipSuccess ||
       (e = hipStreamSynchronize(o->stream)) != hipSuccess) {
@@ -879,6 +882,8 @@ int lslam_ogm_destroy(void* handle) {
   (void)hipSetDevice(o->device);
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   if (o->g.logodds) (void)hipFree(o->g.logodds);
+  if (o->g.steps) (void)hipFree(o->g.steps);
+  if (o->d_values) (void)hipFree(o->d_values);
   if (o->g.counts) (void)hipFree(o->g.counts);
   if (o->d_rays) (void)hipFree(o->d_rays);
   if (o->d_batch) (void)hipFree(o->d_batch);
@@ -895,6 +900,13 @@ int lslam_ogm_set_params(void* handle, double logodds_step, double logodds_clip)
   clear_error();
   if (!handle) return fail(LSLAM_ERR_BAD_ARG, "null handle");
   Ogm* o = static_cast<Ogm*>(handle);
+  if (!(logodds_step > 0.0) || !(logodds_clip > 0.0)) return fail(LSLAM_ERR_BAD_ARG, "log-odds step and clip must be positive");
+  if (logodds_step != o->g.step) {
+    // cells hold (base, n) with value base + n·step: settle them at the old step size before it changes
+    LSLAM_HIP_TRY(hipSetDevice(o->device));
+    LSLAM_HIP_TRY(launch_ogm_values(o->g, o->g.logodds, o->stream));
+    LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+  }
   o->g.step = logodds_step;
   o->g.clip = logodds_clip;
   return LSLAM_OK;
@@ -1038,7 +1050,8 @@ int lslam_ogm_read_logodds(void* handle, float* out) {
   if (!handle || !out) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
   Ogm* o = static_cast<Ogm*>(handle);
   LSLAM_HIP_TRY(hipSetDevice(o->device));
-  LSLAM_HIP_TRY(hipMemcpyAsync(out, o->g.logodds, sizeof(float) * (size_t)o->g.width * o->g.height, hipMemcpyDeviceToHost, o->stream));
+  LSLAM_HIP_TRY(launch_ogm_values(o->g, o->d_values, o->stream));
+  LSLAM_HIP_TRY(hipMemcpyAsync(out, o->d_values, sizeof(float) * (size_t)o->g.width * o->g.height, hipMemcpyDeviceToHost, o->stream));
   LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
   return LSLAM_OK;
 }
@@ -1049,6 +1062,7 @@ int lslam_ogm_write_logodds(void* handle, const float* in) {
   Ogm* o = static_cast<Ogm*>(handle);
   LSLAM_HIP_TRY(hipSetDevice(o->device));
   LSLAM_HIP_TRY(hipMemcpyAsync(o->g.logodds, in, sizeof(float) * (size_t)o->g.width * o->g.height, hipMemcpyHostToDevice, o->stream));
+  LSLAM_HIP_TRY(hipMemsetAsync(o->g.steps, 0, sizeof(int32_t) * (size_t)o->g.width * o->g.height, o->stream));
   LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
   return LSLAM_OK;
 }

@@ -196,7 +196,8 @@ hipError_t run_valu_probe(float* d_scratch, hipStream_t stream, double* lane_ops
 constexpr int kOgmPlanes = 128;  // scans per tile/apply launch pair, each with its own int32 count plane
 
 struct OgmGrid {
-  float* logodds;          // width*height, [x][y]
+  float* logodds;          // width*height, [x][y]: the BASE of the log-odds, value = base + steps·step (float64 sum, rounded once on read)
+  int32_t* steps;          // width*height: net hits − misses accumulated on the base since it was last set (by a clip or a host write)
   int32_t* counts;         // kOgmPlanes planes of width*height hit-miss counts (int16, or int32 for scans above 32767 rays); a plane is valid inside its scan's box only
   int32_t width, height;
   double res, min_x, min_y;
@@ -222,6 +223,7 @@ hipError_t launch_ogm_apply(const OgmGrid& g, const int* d_boxes, int nscans, bo
 void ogm_tile_span(const int* box, int* tiles_x, int* tiles_y);
 constexpr int kOgmBoxEmpty = 0x7f7f7f7f;
 hipError_t launch_ogm_binarize(const OgmGrid& g, uint8_t* out, hipStream_t stream);
+hipError_t launch_ogm_values(const OgmGrid& g, float* out, hipStream_t stream);   // out = f32(base + steps·step); out == g.logodds folds in place (steps ← 0)
 hipError_t launch_ogm_init(const OgmGrid& g, hipStream_t stream);
 
 // ---- LiDAR pre-processing (lslam_preprocess.hip) ----------------------------------------------------

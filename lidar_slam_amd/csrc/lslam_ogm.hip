@@ -20,7 +20,10 @@
 //                     box is then written to the scan's count plane with coalesced row stores, zeros
 //                     included.  Planes are int16 (|count| ≤ rays of the scan), int32 above 32767 rays.
 //   ogm_apply_kernel  one thread per cell walks the planes IN SCAN ORDER inside each plane's box:
-//                     l ← f32(clip(f64(l) + cnt·log 4, ±20)).
+//                     l ← clip(l + cnt·log 4, ±20) in exact arithmetic: a cell is (base, n) with value
+//                     base + n·log 4; a scan adds its count to n, and only a clip (or a host write) moves
+//                     the base.  Integer adds and two compares per plane; the one float64 rounding happens
+//                     when the grid is read (ogm_values_kernel).
 // A plane is only ever read inside the box its tile kernel has just written, so planes are never cleared.
 // Integer counts make the result independent of the order in which rays land.
 #include <hip/hip_runtime.h>
@@ -223,6 +226,25 @@ ogm_tile_kernel(OgmGrid g, const OgmScan* __restrict__ scans, const int4* __rest
       plane[(int64_t)cx * g.height + cy] = (CT)tile[(cx - tx0) * kTilePitch + lane];
 }
 
+__device__ __forceinline__ int clamp_int(double x) { return (int)fmin(fmax(x, -2.0e9), 2.0e9); }
+
+// One cell of the grid while a group of scans is applied to it.
+struct CellState {
+  float base;
+  int n, hi, lo;             // clipped high after a scan ⇔ n > hi, low ⇔ n < lo
+  bool dirty, moved;
+  __device__ __forceinline__ CellState(float base_, int n_, double step, double clip)
+      : base(base_), n(n_), hi(clamp_int(floor((clip - (double)base_) / step))), lo(clamp_int(ceil((-clip - (double)base_) / step))),
+        dirty(false), moved(false) {}
+  __device__ __forceinline__ void add(int c, float fclip, int hi_top, int lo_top, int hi_bottom, int lo_bottom) {
+    if (c == 0) return;
+    n += c;
+    dirty = true;
+    if (n > hi) { base = fclip; n = 0; hi = hi_top; lo = lo_top; moved = true; }
+    else if (n < lo) { base = -fclip; n = 0; hi = hi_bottom; lo = lo_bottom; moved = true; }
+  }
+};
+
 // Two cells (64 apart in y) per thread; planes visited in scan order, each only inside its scan's box.
 // A wave covers 128 consecutive y at one x, so "does this plane's box meet my cells" is decided per wave
 // on scalars (boxes are staged in two registers per lane and broadcast with readlane); lanes outside the
@@ -246,52 +268,69 @@ ogm_apply_kernel(OgmGrid g, const int* __restrict__ boxes, int nplanes, int x0, 
   const int64_t stride = (int64_t)g.width * g.height;
   const int64_t idx0 = (int64_t)cx * g.height + cy0, idx1 = (int64_t)cx * g.height + cy1;
   constexpr int kChunk = 16;
-  float l0 = g.logodds[idx0], l1 = g.logodds[idx1];
-  bool dirty0 = false, dirty1 = false;
+  // value = base + n·step.  "Clipped after this scan" is a comparison of n with two integers that depend on
+  // the base only: base + n·step > clip ⇔ n > ⌊(clip − base)/step⌋, and symmetrically below.
   const double step = g.step, clip = g.clip;
+  CellState a(g.logodds[idx0], g.steps[idx0], step, clip), b(g.logodds[idx1], g.steps[idx1], step, clip);
+  const int hi_at_top = 0, lo_at_top = clamp_int(ceil(-2.0 * clip / step));            // thresholds once the base is +clip
+  const int hi_at_bottom = clamp_int(floor(2.0 * clip / step)), lo_at_bottom = 0;     // … or −clip
+  const float fclip = (float)clip;
   for (int b0 = 0; b0 < nplanes; b0 += kChunk) {
     const bool second = b0 >= 64;
     const int4 bx = second ? boxB : boxA;
-    int c0[kChunk], c1[kChunk];
+    // pass 1: nothing but the loads (no use of a loaded value, so nothing waits) …
+    int r0[kChunk], r1[kChunk];                             // 32-bit: two int16 packed into a register would be a use of the load
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {
       const int src = (b0 & 63) + j;
       const int px0 = __builtin_amdgcn_readlane(bx.x, src), py0 = __builtin_amdgcn_readlane(bx.y, src);
       const int px1 = -__builtin_amdgcn_readlane(bx.z, src), py1 = -__builtin_amdgcn_readlane(bx.w, src);
-      c0[j] = 0; c1[j] = 0;
+      r0[j] = 0; r1[j] = 0;
       if (cx >= px0 && cx <= px1 && wy0 <= py1 && wy1 >= py0) {      // scalar; an empty box fails cx >= px0
         const CT* pl = counts + (int64_t)(b0 + j) * stride;
-        const int v0 = pl[idx0], v1 = pl[idx1];
-        c0[j] = (cy0 >= py0 && cy0 <= py1) ? v0 : 0;
-        c1[j] = (cy1 >= py0 && cy1 <= py1) ? v1 : 0;
+        r0[j] = pl[idx0];
+        r1[j] = pl[idx1];
       }
     }
+    // … pass 2: in scan order, drop what lies outside the plane's box in y, add
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {
-      if (c0[j] != 0) {
-        l0 = (float)fmin(fmax((double)l0 + (double)c0[j] * step, -clip), clip);
-        dirty0 = true;
-      }
-      if (c1[j] != 0) {
-        l1 = (float)fmin(fmax((double)l1 + (double)c1[j] * step, -clip), clip);
-        dirty1 = true;
-      }
+      const int src = (b0 & 63) + j;
+      const int py0 = __builtin_amdgcn_readlane(bx.y, src), py1 = -__builtin_amdgcn_readlane(bx.w, src);
+      const int c0 = (cy0 >= py0 && cy0 <= py1) ? (int)r0[j] : 0;
+      const int c1 = (cy1 >= py0 && cy1 <= py1) ? (int)r1[j] : 0;
+      a.add(c0, fclip, hi_at_top, lo_at_top, hi_at_bottom, lo_at_bottom);
+      b.add(c1, fclip, hi_at_top, lo_at_top, hi_at_bottom, lo_at_bottom);
     }
   }
-  if (dirty0 && live0) g.logodds[idx0] = l0;
-  if (dirty1 && live1) g.logodds[idx1] = l1;
+  if (a.dirty && live0) { g.steps[idx0] = a.n; if (a.moved) g.logodds[idx0] = a.base; }
+  if (b.dirty && live1) { g.steps[idx1] = b.n; if (b.moved) g.logodds[idx1] = b.base; }
+}
+
+__device__ __forceinline__ float cell_value(const OgmGrid& g, int64_t i) {
+  return (float)((double)g.logodds[i] + (double)g.steps[i] * g.step);
+}
+
+// out = f32(base + n·step); with out == g.logodds the grid is folded in place (n ← 0), which a change of the
+// step size needs
+__global__ void ogm_values_kernel(OgmGrid g, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)g.width * g.height) return;
+  const float v = cell_value(g, i);
+  out[i] = v;
+  if (out == g.logodds) g.steps[i] = 0;
 }
 
 __global__ void ogm_binarize_kernel(OgmGrid g, uint8_t* out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)g.width * g.height) return;
-  const float pmf = 1.0f / (1.0f + expf(g.logodds[i]));        // ogm.py:61
+  const float pmf = 1.0f / (1.0f + expf(cell_value(g, i)));    // ogm.py:61
   out[i] = pmf > 0.5f ? 1 : 0;                                 // ogm.py:62-64
 }
 
 __global__ void ogm_init_kernel(OgmGrid g) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (int64_t)g.width * g.height) g.logodds[i] = 0.f;
+  if (i < (int64_t)g.width * g.height) { g.logodds[i] = 0.f; g.steps[i] = 0; }
 }
 
 hipError_t launch_ogm_rays(const OgmGrid& g, const OgmScan* d_scans, int nscans, int max_rays, int4* d_rays, int* d_boxes, int4* d_batch_boxes,
@@ -333,6 +372,11 @@ void ogm_tile_span(const int* box, int* tiles_x, int* tiles_y) {
 hipError_t launch_ogm_binarize(const OgmGrid& g, uint8_t* out, hipStream_t stream) {
   const int64_t n = (int64_t)g.width * g.height;
   hipLaunchKernelGGL(ogm_binarize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, out);
+  return hipGetLastError();
+}
+hipError_t launch_ogm_values(const OgmGrid& g, float* out, hipStream_t stream) {
+  const int64_t n = (int64_t)g.width * g.height;
+  hipLaunchKernelGGL(ogm_values_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, out);
   return hipGetLastError();
 }
 hipError_t launch_ogm_init(const OgmGrid& g, hipStream_t stream) {

@@ -9,8 +9,11 @@ Two update paths are offered:
 * ``update_map_sequential`` – the reference's arithmetic, ray by ray in float32
   with a float64 step (modules/ogm.py:172-188);
 * ``scan_counts`` + ``apply_counts`` – the device formulation: a per-scan int32
-  grid of (hits − misses), then ``l ← f32(clip(f64(l) + cnt·log 4, ±20))`` once
-  per touched cell.  The integer grid is the bit-exact contract; the float
+  grid of (hits − misses), then ``l ← clip(l + cnt·log 4, ±20)`` per touched cell
+  in EXACT arithmetic: a cell is ``(base, n)`` with value ``base + n·log 4``; a scan
+  adds its count to ``n``; only a clip (or an assignment of the grid) moves the base.
+  ``grid_map_log_odds`` is ``f32(base + n·log 4)`` — one float64 rounding however
+  many scans were applied.  The integer grid is the bit-exact contract; the float
   log-odds agree with the sequential path to a few float32 ulps.
 """
 from __future__ import annotations
@@ -89,6 +92,16 @@ class OccupancyGridOracle:
         self.grid_map_log_odds = np.zeros((self.grid_map_width, self.grid_map_height), dtype=np.float32)
         self.logodds_ratio = LOG_ODDS_STEP
 
+    # the log-odds are kept as (float32 base, int64 steps on it); reading rounds once, assigning resets the steps
+    @property
+    def grid_map_log_odds(self):
+        return (self._base.astype(np.float64) + self._steps.astype(np.float64) * LOG_ODDS_STEP).astype(np.float32)
+
+    @grid_map_log_odds.setter
+    def grid_map_log_odds(self, value):
+        self._base = np.array(value, dtype=np.float32)
+        self._steps = np.zeros(self._base.shape, dtype=np.int64)
+
     # -- geometry ----------------------------------------------------------
     def world2grid(self, x, y):
         """ceil((v − min)/res) − 1 per axis in float64, then int32
@@ -140,8 +153,18 @@ class OccupancyGridOracle:
         return cnt
 
     def apply_counts(self, cnt: np.ndarray) -> None:
-        l64 = self.grid_map_log_odds.astype(np.float64) + cnt.astype(np.float64) * LOG_ODDS_STEP
-        self.grid_map_log_odds = np.clip(l64, -LOG_ODDS_CLIP, LOG_ODDS_CLIP).astype(np.float32)
+        """one scan: n += cnt on the touched cells, then the clip of modules/ogm.py:188 as integer thresholds —
+        base + n·step > clip  ⇔  n > ⌊(clip − base)/step⌋ (and symmetrically below)."""
+        base, n = self._base, self._steps
+        b64 = base.astype(np.float64)
+        hi = np.floor((LOG_ODDS_CLIP - b64) / LOG_ODDS_STEP)
+        lo = np.ceil((-LOG_ODDS_CLIP - b64) / LOG_ODDS_STEP)
+        touched = cnt != 0
+        n[touched] += cnt[touched]
+        above = touched & (n > hi)
+        below = touched & ~above & (n < lo)
+        base[above] = LOG_ODDS_CLIP; n[above] = 0
+        base[below] = -LOG_ODDS_CLIP; n[below] = 0
 
     def update_map(self, x_t, z_t) -> None:
         self.apply_counts(self.scan_counts(x_t, z_t))
@@ -150,7 +173,7 @@ class OccupancyGridOracle:
     def update_map_sequential(self, x_t, z_t) -> None:
         """Ray-by-ray float32 accumulation with a float64 step, clip once per scan
         (modules/ogm.py:172-188)."""
-        g = self.grid_map_log_odds
+        g = self.grid_map_log_odds                      # a float32 copy; assigned back (steps reset) below
         start, ends = self.ray_endpoints(x_t, z_t)
         for e in ends:
             cells = self._valid_cells(start, e)
