@@ -27,7 +27,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_scans, out_dir):
+def test_interleaved_assignment_covers_everything_once():
+    from lidar_slam_amd.shard import owned_pairs
+    for S in (0, 1, 7, 4955):
+        for world in (1, 2, 8):
+            own = [owned_pairs(S, world, r, "interleaved") for r in range(world)]
+            assert np.array_equal(np.sort(np.concatenate(own)), np.arange(S))
+            assert max(o.shape[0] for o in own) - min(o.shape[0] for o in own) <= 1
+    with pytest.raises(ValueError):
+        owned_pairs(4, 2, 0, "random")
+
+
+def _worker(rank, world, port, n_scans, out_dir, assignment="contiguous"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -44,16 +55,21 @@ def _worker(rank, world, port, n_scans, out_dir):
         return np.array([icp_oracle.run_icp_full(z_block[i + 1], z_block[i], init_T[i], epsilon=0.001).T
                          for i in range(len(z_block) - 1)]).reshape(-1, 4, 4)
 
+    def oracle_pair_solver(sources, targets, init_T):
+        return np.array([icp_oracle.run_icp_full(s_, t_, T0, epsilon=0.001).T
+                         for s_, t_, T0 in zip(sources, targets, init_T)]).reshape(-1, 4, 4)
+
     poses, rel = poses_from_scan_matching_sharded(g["x_ts"][:n_scans], z, return_relative_poses=True,
-                                                  solver=oracle_solver)
+                                                  solver=oracle_solver if assignment == "contiguous" else oracle_pair_solver,
+                                                  assignment=assignment)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), poses=poses, rel=rel)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_scans", [12, 9])          # even and ragged split of the pairs
-def test_two_rank_gloo_matches_unsharded_reference(tmp_path, n_scans):
+@pytest.mark.parametrize("n_scans,assignment", [(12, "contiguous"), (9, "contiguous"), (10, "interleaved")])   # even and ragged splits
+def test_two_rank_gloo_matches_unsharded_reference(tmp_path, n_scans, assignment):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, n_scans, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, n_scans, str(tmp_path), assignment), nprocs=2, join=True)
     g = golden("seq_scanmatch.npz")
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     assert np.array_equal(r0["poses"], r1["poses"]) and np.array_equal(r0["rel"], r1["rel"])
