@@ -353,7 +353,14 @@ def other_config(name, a, torch, device, stream, timed):
         out = {"workload": "C2 single planar pair 1081x1081, 50 forced iterations", "ms_one_workgroup": ms, "ms_whole_chip": ms_chip,
                "ms": min(ms, ms_chip), "iterations_per_sec": a.iters / (min(ms, ms_chip) * 1e-3),
                "pose_err_vs_truth": float(np.abs(res["r"][0] - T_true).max()),
-               "paths_agree": float(np.abs(res["r"][0] - oT[0].cpu().numpy()).max())}
+               "paths_agree": float(np.abs(res["r"][0] - oT[0].cpu().numpy()).max()),
+               "roofline": {"kernel": "nn_tiled_kernel<2,1,true> (search + fused key reduction, moments, solve: one launch per iteration)",
+                            "bound": "launch latency", "us_per_iteration": ms_chip * 1e3 / a.iters,
+                            "achieved": a.iters * 1081.0 * 1081 * 5 / (ms_chip * 1e-3) / 1e12, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                            "frac": a.iters * 1081.0 * 1081 * 5 / (ms_chip * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
+                            "hbm_effective_frac_of_8TBps": a.iters * 1081.0 * 1081 * 8 / (ms_chip * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                            "note": "1.17 M pair evaluations per iteration are 0.1 us of chip time; an iteration is one dependent kernel launch "
+                                    "(about 6 us of dispatch + the serial solve of the last workgroup)"}}
     elif name == "c5":
         src, tgt, T_true, T0 = synth.cloud_c5()
         s = torch.from_numpy(src).to(device); t = torch.from_numpy(tgt).to(device)
@@ -372,7 +379,10 @@ def other_config(name, a, torch, device, stream, timed):
                "roofline": {"kernel": "nn_tiled_kernel<3,4> (+ moments_kernel<3>, solve_kernel<3> per iteration)", "bound": "valu",
                             "achieved": it * 1e10 * 8 / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                             "frac": it * 1e10 * 8 / (ms * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
-                            "note": "8 algorithmic flop per 3-D pair evaluation; whole iteration (3 launches) timed, not the search kernel alone"},
+                            "hbm_effective_untiled_TBps": it * 1e10 * 12 / (ms * 1e-3) / 1e12,
+                            "hbm_effective_frac_of_8TBps": it * 1e10 * 12 / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                            "hbm_compulsory_bytes_per_iteration": 12 * 2 * 100000 + 4 * 100000,
+                            "note": "8 algorithmic flop and 12 untiled bytes per 3-D pair evaluation; whole iteration (3 launches) timed, not the search kernel alone"},
                "pruned": {"what": "same 20 iterations with LSLAM_ICP_PRUNE (Morton sort + box hierarchy, exact results; the sort is inside the timed call)",
                           "ms": ms_p, "speedup": ms / ms_p, "max_abs_T_difference": float(np.abs(res["p"][0] - T).max())},
                "pose_err_vs_truth": float(np.abs(T - T_true).max())}
