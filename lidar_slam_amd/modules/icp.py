@@ -109,6 +109,11 @@ def get_error(pc1, pc2, normalize=False):
     return np.float64(out[0])
 
 
+# float32 points resolve 6e-5 m at |coordinate| = 1000 m; clouds further out than this are shifted towards
+# the origin in float64 before they are rounded (sensor-frame LiDAR scans never are: ±30 m)
+CENTRE_ABOVE = 1000.0
+
+
 def _solve(pc1, pc2, init_transform, epsilon, max_iters, stopping_thresh, normalize_error):
     """-> (T (4,4) f64, error f64, correspondences int64)"""
     src = np.asarray(pc1)
@@ -116,6 +121,23 @@ def _solve(pc1, pc2, init_transform, epsilon, max_iters, stopping_thresh, normal
     if src.ndim != 2 or tgt.ndim != 2 or src.shape[1] < 2 or tgt.shape[1] < 2:
         raise ValueError("point clouds must be (N,2) or (N,3)")
     T0 = np.array(init_transform, dtype=np.float64).reshape(4, 4)
+    if tgt.shape[0] and src.shape[0] and np.isfinite(T0).all():
+        reach = max(np.abs(tgt[:, :3]).max(), np.abs(src[:, :3]).max())
+        if np.isfinite(reach) and reach > CENTRE_ABOVE:
+            # q ≈ R p + t  ⇔  q − c ≈ R (p − c) + (R c + t − c): solve in coordinates relative to the target's centroid
+            d = min(src.shape[1], tgt.shape[1], 3)
+            c = np.zeros(3)
+            c[:d] = np.mean(np.asarray(tgt[:, :d], dtype=np.float64), axis=0)
+            shift = lambda pc: np.asarray(pc[:, :3], dtype=np.float64) - c[: min(pc.shape[1], 3)]
+            Tc = T0.copy()
+            Tc[:3, 3] = T0[:3, :3] @ c + T0[:3, 3] - c
+            T, err, corr = _solve_near(shift(src), shift(tgt), Tc, epsilon, max_iters, stopping_thresh, normalize_error)
+            T[:3, 3] = T[:3, 3] + c - T[:3, :3] @ c
+            return T, err, corr
+    return _solve_near(src, tgt, T0, epsilon, max_iters, stopping_thresh, normalize_error)
+
+
+def _solve_near(src, tgt, T0, epsilon, max_iters, stopping_thresh, normalize_error):
     planar = src.shape[1] == 2 and tgt.shape[1] == 2 and _keeps_planar(T0)
     if planar:
         s32 = np.ascontiguousarray(src, dtype=np.float32)

@@ -140,6 +140,24 @@ def test_register_multi_start_matches_reference_loop(icp, sequential, monkeypatc
     np.testing.assert_allclose(W.yaw_starts(g["src"], g["tgt"])[[0, 4, 5, 13]], g["init"], atol=1e-12)
 
 
+def test_clouds_far_from_the_origin_are_centred_before_rounding(icp):
+    """at |coordinate| = 1e5 m a float32 holds 8 mm; run_icp shifts such clouds in float64 first"""
+    from oracle import icp_oracle
+    rng = np.random.default_rng(3)
+    tgt = rng.uniform(-5, 5, (300, 2)) + np.array([1.0e5, -2.0e5])
+    th = 0.02
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    c = tgt.mean(0)
+    src = (tgt[:250] - c) @ R.T + c + np.array([0.03, -0.02]) + rng.normal(0, 0.002, (250, 2))
+    T, err, corr = icp.run_icp(src, tgt, return_error=True, return_correspondences=True, epsilon=1e-9)
+    o = icp_oracle.run_icp_full(src, tgt, None, epsilon=1e-9)
+    assert np.array_equal(corr, o.correspondences)
+    assert abs(err - o.error) < 1e-5 * o.error                 # float32 rounding of the centred points (±5 m)
+    p = np.c_[src, np.zeros(len(src)), np.ones(len(src))]
+    assert np.abs(p @ T.T - p @ o.T.T).max() < 1e-4            # same alignment of the points (t alone is R·1e5-conditioned)
+    assert np.abs(T[:3, :3] - o.T[:3, :3]).max() < TOL_ROT
+
+
 def test_get_transform_get_error_get_correspondences(icp):
     from oracle import c_oracle
     g = golden("kabsch.npz")
