@@ -18,7 +18,8 @@ from .._lib import check, lib, ptr
 from ..batch import icp_batch
 
 # one workgroup iterates a pair on chip; beyond this many pair evaluations per iteration the
-# whole-chip path (grid-wide LDS-tiled search, three launches ≈ 10 µs per iteration) is faster
+# whole-chip path (grid-wide LDS-tiled search; one launch ≈ 12 µs per iteration below 8192 source
+# points, three launches above) is faster
 LARGE_PAIR_EVALS = 300_000
 
 _DEVICE = 0

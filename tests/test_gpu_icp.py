@@ -232,7 +232,7 @@ def test_launch_geometry_does_not_change_results(icp, env, monkeypatch):
 
 
 def test_large_path_equals_batch_path(icp):
-    """the whole-chip path (3 launches / iteration) and the one-workgroup path agree"""
+    """the whole-chip path (one fused or three launches per iteration) and the one-workgroup path agree"""
     from lidar_slam_amd import _lib
     from lidar_slam_amd._lib import check, lib, ptr
     g = golden("icp_planar.npz")
@@ -336,10 +336,13 @@ def test_ragged_random_batch_matches_exact_oracle(icp, dim):
         np.testing.assert_allclose(r.error[k], eo, rtol=1e-9, atol=1e-18)
 
 
-@pytest.mark.parametrize("dim,n,m", [(2, 700, 5000), (3, 9000, 3000), (2, 70000, 1200), (3, 300, 40000)])
-def test_whole_chip_path_random_shapes_match_exact_oracle(icp, dim, n, m):
-    """the three-launch path over its geometry regimes (P = 1/2/4, one and many splits)"""
+@pytest.mark.parametrize("dim,n,m,fuse", [(2, 700, 5000, 1), (2, 700, 5000, 0), (3, 9000, 3000, 1), (2, 70000, 1200, 1),
+                                           (3, 300, 40000, 1), (3, 300, 40000, 0), (2, 8191, 900, 1)])
+def test_whole_chip_path_random_shapes_match_exact_oracle(icp, dim, n, m, fuse, monkeypatch):
+    """the whole-chip path over its geometry regimes (P = 1/2/4, one and many splits; below 8192 source points
+    one fused launch per iteration, or three with LSLAM_ICP_FUSE_TAIL=0)"""
     from lidar_slam_amd import _lib
+    monkeypatch.setenv("LSLAM_ICP_FUSE_TAIL", str(fuse))
     from lidar_slam_amd._lib import check, lib, ptr
     from oracle import c_oracle
     rng = np.random.default_rng(n + m)
