@@ -221,6 +221,18 @@ def main():
                                 "ms_per_step": ms_p, "icp_iterations_per_sec": S * I / (ms_p * 1e-3),
                                 "speedup_vs_all_pairs_sweep": (dt / a.steps * 1e3) / ms_p,
                                 "max_abs_T_difference": float((oT2 - out_T).abs().max().item())}
+        if rank == 0 and world == 1:
+            # the same batch left to the reference's own stop rules (scan-matching call: epsilon 1e-3, defaults else)
+            oT3 = torch.empty_like(out_T)
+            def step_natural():
+                B.icp_batch_dev(src.data_ptr(), off.data_ptr(), tgt.data_ptr(), off.data_ptr(), 2, init.data_ptr(), S, P, P,
+                                oT3.data_ptr(), out_err.data_ptr(), out_it.data_ptr(), None, epsilon=0.001,
+                                max_iters=2000, stopping_thresh=0.0001, stream=stream)
+            ms_n = _time(torch, step_natural, 1, 3)
+            its = int(out_it.sum().item())
+            result["natural_convergence"] = {"what": "same batch, stop rules of the scan-matching call (epsilon 1e-3, stopping_thresh 1e-4, max_iters 2000)",
+                                             "ms_per_step": ms_n, "iterations_total": its, "iterations_min_max": [int(out_it.min().item()), int(out_it.max().item())],
+                                             "icp_iterations_per_sec": its / (ms_n * 1e-3), "scan_pairs_per_sec": S / (ms_n * 1e-3)}
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             n = min(a.cpu_sample_pairs, S)
             h_src, h_tgt, h_init = src[: n * P].cpu().numpy().astype(np.float64), tgt[: n * P].cpu().numpy().astype(np.float64), init[:n].cpu().numpy()
