@@ -116,6 +116,11 @@ def cpu_baseline_all_cores(src, tgt, init, P, n_pairs, iters):
 # ------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
+    # Libraries talk on stdout (RCCL prints a version banner when its first communicator comes up): everything but
+    # the one JSON line goes to stderr, whoever writes it.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -247,10 +252,12 @@ def main():
     if rank == 0 and world == 1 and a.workload == "c4" and not a.no_other_configs:
         result["other_configs"] = {k: other_config(k, a, torch, device, stream, timed=False) for k in ("c2", "c3", "c5", "ogm", "filter_lidar")}
 
-    if rank == 0:
-        print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
 
 
 _SEQ = {}
