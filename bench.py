@@ -284,7 +284,7 @@ def other_config(name, a, torch, device, stream, timed):
         from lidar_slam_amd.modules import localization as L
         # a small flat (±4.5 m): DBSCAN(0.1, 10) only keeps surfaces closer than ≈4 m (beam spacing < 2 cm),
         # as in the reference's real scan where 707 of 1076 points survive
-        seq = synth.sequence_c3(4956, seed=21, drop=(0.0, 0.05), half=4.5, n_obstacles=6)
+        seq = synth.sequence_c3(4956, seed=24, drop=(0.0, 0.05), half=4.5, n_obstacles=4)
         L.preprocess_lidar(seq.ranges[:64], 0.1, 30.0, dbscan=(0.1, 10), k_std=2)                  # warm-up
         t0 = time.perf_counter()
         z = L.preprocess_lidar(seq.ranges, 0.1, 30.0, dbscan=(0.1, 10), k_std=2)
