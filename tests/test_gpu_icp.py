@@ -1,5 +1,4 @@
 """Parity of the HIP ICP path (through the C ABI) with the oracle and the reference's golden vectors."""
-import os
 
 import numpy as np
 import pytest

@@ -1,6 +1,5 @@
 """The C restatement (oracle/csrc/oracle_icp.c) against the golden vectors and the NumPy oracle."""
 import numpy as np
-import pytest
 
 from conftest import golden, split
 from oracle import c_oracle, icp_oracle

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
-from conftest import ROOT, golden, split
+from conftest import ROOT, golden
 
 
 def test_partition_covers_everything_once():
