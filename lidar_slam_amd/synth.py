@@ -196,3 +196,37 @@ def cloud_c5(N: int = 100_000, M: int = 100_000, seed: int = 5):
     Ti = np.linalg.inv(T)
     src = p @ Ti[:3, :3].T + Ti[:3, 3]
     return src.astype(np.float32), tgt.astype(np.float32), T, np.eye(4)
+
+
+def _drill_surface(rng, n):
+    """points on a drill-like object, metres: a box (body), a cylinder under it (handle), a thin cylinder in
+    front (bit) — no symmetry, so only one of the yaw starts lands in the right basin"""
+    k = n // 3
+    f = rng.integers(0, 3, k); u, v = rng.uniform(-1, 1, k), rng.uniform(-1, 1, k); sgn = rng.choice([-1.0, 1.0], k)
+    half = np.array([0.09, 0.03, 0.035])
+    body = np.where((f == 0)[:, None], np.column_stack((sgn, u, v)), np.where((f == 1)[:, None], np.column_stack((u, sgn, v)), np.column_stack((u, v, sgn)))) * half
+    a, z = rng.uniform(0, 2 * np.pi, k), rng.uniform(-0.13, -0.035, k)
+    handle = np.column_stack((-0.04 + 0.018 * np.cos(a), 0.018 * np.sin(a), z))
+    a, x = rng.uniform(0, 2 * np.pi, n - 2 * k), rng.uniform(0.09, 0.16, n - 2 * k)
+    bit = np.column_stack((x, 0.006 * np.cos(a), 0.006 * np.sin(a)))
+    return np.vstack((body, handle, bit))
+
+
+def drill_c1(n_model: int = 6000, n_view: int = 4000, n_targets: int = 4, seed: int = 1):
+    """config C1 (code/icp_warm_up/test_icp.py): a canonical object model and `n_targets` measured partial views of
+    it, each seen from another yaw (any of the 24 yaw starts may be the good one) with a small tilt and offset.
+    Returns (model (n_model,3) f64, [views (≈n_view,3) f64], [T_true model→view])."""
+    rng = np.random.default_rng(seed)
+    model = _drill_surface(rng, n_model)
+    views, truths = [], []
+    for k in range(n_targets):
+        yaw, tilt = rng.uniform(0, 2 * np.pi), rng.uniform(-0.1, 0.1)
+        Rz = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(tilt), -np.sin(tilt)], [0, np.sin(tilt), np.cos(tilt)]])
+        R, t = Rz @ Rx, rng.uniform(-0.3, 0.3, 3)
+        pts = _drill_surface(rng, 2 * n_view)
+        pts = pts[pts @ np.array([0.3, 0.8, 0.52]) > -0.045][:n_view]          # the sensor misses the far side of the object
+        views.append(pts @ R.T + t + rng.normal(0, 0.0005, pts.shape))
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+        truths.append(T)
+    return model, views, truths
