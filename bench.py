@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--points", type=int, default=4096, help="points per cloud (c4)")
     ap.add_argument("--iters", type=int, default=50, help="forced ICP iterations per pair (c4/c2/c5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--natural", action="store_true", help="also time the C4 batch under the reference's own stop rules")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=256)
     return ap.parse_args()
@@ -226,8 +227,10 @@ def main():
                                 "ms_per_step": ms_p, "icp_iterations_per_sec": S * I / (ms_p * 1e-3),
                                 "speedup_vs_all_pairs_sweep": (dt / a.steps * 1e3) / ms_p,
                                 "max_abs_T_difference": float((oT2 - out_T).abs().max().item())}
-        if rank == 0 and world == 1:
-            # the same batch left to the reference's own stop rules (scan-matching call: epsilon 1e-3, defaults else)
+        if rank == 0 and world == 1 and a.natural:
+            # the same batch left to the reference's own stop rules (scan-matching call: epsilon 1e-3, defaults else).
+            # Opt-in: it launches the headline kernel with a tenth of the work, which would blur that kernel's
+            # average duration in a rocprofv3 --stats summary of the run.
             oT3 = torch.empty_like(out_T)
             def step_natural():
                 B.icp_batch_dev(src.data_ptr(), off.data_ptr(), tgt.data_ptr(), off.data_ptr(), 2, init.data_ptr(), S, P, P,
