@@ -257,12 +257,18 @@ struct LargeWs {
   double* partials = nullptr;
   LargeState* state = nullptr;
   LargeState* h_state = nullptr;       // pinned
+  LargeState* h_back[2] = {nullptr, nullptr};   // pinned read-back slots of alternating polls
+  hipEvent_t polled[2] = {nullptr, nullptr};
   int ensure(int dev, int64_t n) {
     if (dev != device) { release(); device = dev; }
     if (!partials) {
       LSLAM_HIP_TRY(hipMalloc(&partials, sizeof(double) * (size_t)kMomMaxBlocks * 32));
       LSLAM_HIP_TRY(hipMalloc(&state, sizeof(LargeState)));
       LSLAM_HIP_TRY(hipHostMalloc(&h_state, sizeof(LargeState)));
+      for (int i = 0; i < 2; ++i) {
+        LSLAM_HIP_TRY(hipHostMalloc(&h_back[i], sizeof(LargeState)));
+        LSLAM_HIP_TRY(hipEventCreateWithFlags(&polled[i], hipEventDisableTiming));
+      }
     }
     if (n > keys_cap) {
       if (keys) (void)hipFree(keys);
@@ -277,6 +283,11 @@ struct LargeWs {
     if (partials) (void)hipFree(partials);
     if (state) (void)hipFree(state);
     if (h_state) (void)hipHostFree(h_state);
+    for (int i = 0; i < 2; ++i) {
+      if (h_back[i]) (void)hipHostFree(h_back[i]);
+      if (polled[i]) (void)hipEventDestroy(polled[i]);
+      h_back[i] = nullptr; polled[i] = nullptr;
+    }
     keys = nullptr; partials = nullptr; state = nullptr; h_state = nullptr; keys_cap = 0;
   }
 };
@@ -373,11 +384,14 @@ int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64
   sa.state = ws.state; sa.partials = ws.partials; sa.rows = rows; sa.flags = flags;
   sa.epsilon = epsilon; sa.stopping_thresh = stopping_thresh; sa.max_iters = max_iters;
 
-  // at most max_iters + 1 iterations run (icp.py:174); enqueue in groups and poll the flag between
+  // At most max_iters + 1 iterations run (icp.py:174).  Iterations are enqueued in groups (poll_every, then twice
+  // as many each time, up to 32) and the state is read back after each group; the NEXT group is already in the
+  // queue when the host waits for a read-back, so the GPU never idles on a poll.  Launches past convergence return
+  // at once on the `done` flag.
   const int64_t cap = (int64_t)max_iters + 1;
   int64_t launched = 0;
-  for (;;) {
-    for (int k = 0; k < poll_every && launched < cap; ++k, ++launched) {
+  auto enqueue_group = [&](int count, int slot) -> int {
+    for (int k = 0; k < count && launched < cap; ++k, ++launched) {
       if (prune) {
         LpNnArgs pa{};
         pa.src_sorted = lp.src_sorted; pa.n = n; pa.tgt_sorted = lp.tgt_sorted; pa.tgt_index = lp.tgt_index; pa.m = m;
@@ -395,9 +409,22 @@ int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64
       }
       LSLAM_HIP_TRY(launch_solve(sa, dim, st));
     }
-    LSLAM_HIP_TRY(hipMemcpyAsync(hs, ws.state, sizeof(LargeState), hipMemcpyDeviceToHost, st));
-    LSLAM_HIP_TRY(hipStreamSynchronize(st));
-    if (hs->done || launched >= cap) break;
+    LSLAM_HIP_TRY(hipMemcpyAsync(ws.h_back[slot], ws.state, sizeof(LargeState), hipMemcpyDeviceToHost, st));
+    LSLAM_HIP_TRY(hipEventRecord(ws.polled[slot], st));
+    return LSLAM_OK;
+  };
+  int group = poll_every, slot = 0;
+  if ((rc = enqueue_group(group, slot)) != LSLAM_OK) return rc;
+  for (;;) {
+    const bool more = launched < cap;
+    if (more) {
+      group = group * 2 > 32 ? (group > 32 ? group : 32) : group * 2;
+      if ((rc = enqueue_group(group, slot ^ 1)) != LSLAM_OK) return rc;
+    }
+    LSLAM_HIP_TRY(hipEventSynchronize(ws.polled[slot]));
+    hs = ws.h_back[slot];
+    if (hs->done || !more) break;
+    slot ^= 1;
   }
   memcpy(out_T, hs->T, sizeof(double) * 16);
   *out_err = hs->err;
