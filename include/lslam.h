@@ -217,14 +217,17 @@ int lslam_scans_match_sequence(void *scans, const double *init_T,
                                double *out_T, double *out_err, int32_t *out_iters);
 
 /* ---- occupancy grid: modules/ogm.py ------------------------------------- */
-/* OccupancyGridMap state (ogm.py:37-43) resident in HBM: float32 log-odds
- * (width x height, indexed [x_cell][y_cell], ogm.py:41) plus an int32 hit/miss
- * scratch grid. */
+/* OccupancyGridMap state (ogm.py:37-43) resident in HBM: the log-odds grid
+ * (width x height, indexed [x_cell][y_cell], ogm.py:41) as a float32 base plus an
+ * int32 count of log-odds steps on it — a scan adds its (hits - misses) to the
+ * count, the clip of ogm.py:188 (or a write) moves the base, and a read returns
+ * f32(base + count * step): the recurrence in exact arithmetic, one rounding —
+ * plus per-scan hit/miss scratch planes (allocated on the first update). */
 int lslam_ogm_create(double res, double world_min_x, double world_min_y,
                      int32_t width, int32_t height, double logodds_step, double logodds_clip,
                      int device, void **out_handle);
 int lslam_ogm_destroy(void *handle);
-/* the reference keeps the step in a public attribute (ogm.py:43 logodds_ratio) */
+/* the reference keeps the step in a public attribute (ogm.py:43 logodds_ratio); both must be > 0 */
 int lslam_ogm_set_params(void *handle, double logodds_step, double logodds_clip);
 
 /* update_map (ogm.py:149-188) for K scans applied IN ORDER (the per-scan clip makes
