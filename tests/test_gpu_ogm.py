@@ -133,3 +133,31 @@ def test_scan_with_more_rays_than_int16_counts_hold():
     grid.update_map(pose, scan)
     orc.apply_counts(ref)
     np.testing.assert_array_equal(grid.grid_map_log_odds, orc.grid_map_log_odds)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_map_geometries_match_oracle(seed):
+    """random resolutions, extents (from a few cells to several tiles, off-centre worlds), buffers and poses"""
+    from lidar_slam_amd.modules.ogm import OccupancyGridMap
+    from oracle.ogm_oracle import OccupancyGridOracle
+    rng = np.random.default_rng(100 + seed)
+    res = float(rng.choice([0.02, 0.05, 0.1, 0.25, 1.0]))
+    wx, wy = rng.uniform(0.5, 12.0) * (1 + 10 * (res >= 0.25)), rng.uniform(0.5, 12.0) * (1 + 10 * (res >= 0.25))
+    cx, cy = rng.uniform(-50, 50, 2)
+    args = (res, cx + wx, cy + wy, cx - wx, cy - wy, float(rng.choice([1.0, 0.0, 2.5])))
+    grid, orc = OccupancyGridMap(*args), OccupancyGridOracle(*args)
+    assert grid.grid_map.shape == orc.grid_map.shape
+    poses, scans = [], []
+    for _ in range(6):
+        poses.append([cx + rng.uniform(-1.2, 1.2) * wx, cy + rng.uniform(-1.2, 1.2) * wy, rng.uniform(-np.pi, np.pi)])
+        n = int(rng.integers(1, 400))
+        a, r = rng.uniform(-np.pi, np.pi, n), rng.uniform(0.0, 3.0 * max(wx, wy), n)
+        scans.append(np.column_stack((r * np.cos(a), r * np.sin(a))))
+    for p, z in zip(poses[:2], scans[:2]):                              # per-scan integer grids, then one by one …
+        np.testing.assert_array_equal(grid.scan_counts(np.array(p), z), orc.scan_counts(np.array(p), z))
+        grid.update_map(np.array(p), z); orc.update_map(np.array(p), z)
+    np.testing.assert_array_equal(grid.grid_map_log_odds, orc.grid_map_log_odds)
+    grid.build_map(np.array(poses[2:]), scans[2:])                       # … and the rest in one call, on top
+    orc.build_map(np.array(poses[2:]), scans[2:])
+    np.testing.assert_array_equal(grid.grid_map_log_odds, orc.grid_map_log_odds)
+    np.testing.assert_array_equal(grid.grid_map, orc.grid_map)
