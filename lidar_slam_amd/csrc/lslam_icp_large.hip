@@ -21,6 +21,8 @@
 // and ticket for the next launch.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "lslam_device.h"
 #include "lslam_kernels.h"
 
@@ -361,7 +363,8 @@ NnGeometry nn_geometry(int dim, int64_t n, int64_t m) {
   if (want > kNnMaxSplits) want = kNnMaxSplits;
   const int tile_max = (dim == 2) ? kNnTilePlanar : kNnTile3D;
   int64_t tile = ((m + want - 1) / want + CHUNK - 1) / CHUNK * CHUNK;
-  if (tile < kNnTileMin) tile = kNnTileMin;
+  static const int tile_min = [] { const char* e = getenv("LSLAM_NN_TILE_MIN"); const int v = e ? atoi(e) : kNnTileMin; return v < 16 ? 16 : v; }();
+  if (tile < tile_min) tile = (tile_min + CHUNK - 1) / CHUNK * CHUNK;
   if (tile > tile_max) tile = tile_max;
   const int64_t tiles_total = (m + tile - 1) / tile;
   int64_t tiles_per_split = tiles_total / want;
