@@ -413,18 +413,25 @@ int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64
     LSLAM_HIP_TRY(hipEventRecord(ws.polled[slot], st));
     return LSLAM_OK;
   };
+  // The first group is waited for on its own (most LiDAR-sized problems converge inside it, and launches queued
+  // past convergence would delay the caller's next call); from the second group on the queue is kept one group ahead.
   int group = poll_every, slot = 0;
   if ((rc = enqueue_group(group, slot)) != LSLAM_OK) return rc;
+  bool ahead = false;                                       // is a group already queued behind the one being waited for?
   for (;;) {
-    const bool more = launched < cap;
-    if (more) {
+    LSLAM_HIP_TRY(hipEventSynchronize(ws.polled[slot]));
+    hs = ws.h_back[slot];
+    if (hs->done || (!ahead && launched >= cap)) break;
+    if (!ahead) {                                           // first poll said "not yet": queue the next group now …
       group = group * 2 > 32 ? (group > 32 ? group : 32) : group * 2;
       if ((rc = enqueue_group(group, slot ^ 1)) != LSLAM_OK) return rc;
     }
-    LSLAM_HIP_TRY(hipEventSynchronize(ws.polled[slot]));
-    hs = ws.h_back[slot];
-    if (hs->done || !more) break;
-    slot ^= 1;
+    slot ^= 1;                                              // … that group is what we wait for next,
+    ahead = launched < cap;
+    if (ahead) {                                            // and one more goes behind it
+      group = group * 2 > 32 ? (group > 32 ? group : 32) : group * 2;
+      if ((rc = enqueue_group(group, slot ^ 1)) != LSLAM_OK) return rc;
+    }
   }
   memcpy(out_T, hs->T, sizeof(double) * 16);
   *out_err = hs->err;
