@@ -73,3 +73,37 @@ def register_multi_start(source_pc, target_pc, n_starts=24, epsilon=0.001, voxel
     if return_all:
         out += (poses, errors, iters)
     return out
+
+
+def register_multi_start_many(source_pc, target_pcs, n_starts=24, epsilon=0.001, voxel_size=0.005,
+                              downsample_above=20000, max_iters=2000, stopping_thresh=0.0001):
+    """The outer loop of test_icp.py:66-92 as well: every measured cloud × every yaw start in ONE launch (one
+    workgroup per run; with 4 views × 24 starts that is 96 compute units busy instead of 24).  Returns a list of
+    ``(best_pose, best_error)``, one per target, each equal to what ``register_multi_start`` returns for it."""
+    source_pc = np.asarray(source_pc)
+    targets = [np.asarray(t) for t in target_pcs]
+    d = 2 if source_pc.shape[1] == 2 and all(t.shape[1] == 2 for t in targets) else 3
+    src_blocks, tgt_blocks, inits, n_src, n_tgt = [], [], [], [], []
+    for t in targets:
+        inits.append(yaw_starts(source_pc, t, n_starts))         # centroids of the FULL clouds (test_icp.py:72-74)
+        if source_pc.shape[0] > downsample_above or t.shape[0] > downsample_above:
+            s_ds, t_ds = icp.voxel_downsample(source_pc, voxel_size), icp.voxel_downsample(t, voxel_size)
+        else:
+            s_ds, t_ds = source_pc, t
+        src_blocks.append(np.ascontiguousarray(icp._xyz(s_ds)[:, :d], dtype=np.float32))
+        tgt_blocks.append(np.ascontiguousarray(icp._xyz(t_ds)[:, :d], dtype=np.float32))
+        n_src.append(src_blocks[-1].shape[0]); n_tgt.append(tgt_blocks[-1].shape[0])
+    if not targets:
+        return []
+    src = np.vstack([np.tile(b, (n_starts, 1)) for b in src_blocks])
+    tgt = np.vstack([np.tile(b, (n_starts, 1)) for b in tgt_blocks])
+    src_off = np.concatenate(([0], np.cumsum(np.repeat(n_src, n_starts)))).astype(np.int64)
+    tgt_off = np.concatenate(([0], np.cumsum(np.repeat(n_tgt, n_starts)))).astype(np.int64)
+    r = icp_batch(src, src_off, tgt, tgt_off, np.concatenate(inits), epsilon=epsilon, max_iters=max_iters,
+                  stopping_thresh=stopping_thresh, normalize_error=True, device=icp._DEVICE)
+    out = []
+    for v in range(len(targets)):
+        e = r.error[v * n_starts:(v + 1) * n_starts]
+        best = int(np.argmin(e))                                   # first index of the minimum = the reference's strict <
+        out.append((r.T[v * n_starts + best].copy(), np.float64(e[best])))
+    return out

@@ -139,6 +139,19 @@ def test_register_multi_start_matches_reference_loop(icp, sequential, monkeypatc
     np.testing.assert_allclose(W.yaw_starts(g["src"], g["tgt"])[[0, 4, 5, 13]], g["init"], atol=1e-12)
 
 
+def test_register_multi_start_many_equals_one_target_at_a_time(icp):
+    from lidar_slam_amd import icp_warm_up as W
+    g = golden("icp_3d.npz")
+    rng = np.random.default_rng(4)
+    targets = [g["tgt"], g["tgt"][::2] + 0.001, g["tgt"][100:] @ np.array([[0.0, -1, 0], [1, 0, 0], [0, 0, 1.0]])]
+    many = W.register_multi_start_many(g["src"], targets)
+    for (pose, err), t in zip(many, targets):
+        p1, e1 = W.register_multi_start(g["src"], t)
+        np.testing.assert_array_equal(pose, p1)
+        assert err == e1
+    assert W.register_multi_start_many(g["src"], []) == []
+
+
 def test_clouds_far_from_the_origin_are_centred_before_rounding(icp):
     """at |coordinate| = 1e5 m a float32 holds 8 mm; run_icp shifts such clouds in float64 first"""
     from oracle import icp_oracle
