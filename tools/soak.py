@@ -1,0 +1,72 @@
+"""Randomised soak of the HIP ICP paths against the C oracle's device recipe (exact fmaf): many ragged batches of
+random planar / 3-D problems, sizes from a handful to a few thousand points, duplicated targets, grid-aligned ties.
+Every problem must give identical iteration counts and correspondences and T within 1e-9 — on the all-pairs path,
+on the pruned path and (for the larger ones) on the whole-chip path.
+
+    python tools/soak.py [seconds] [seed]        # prints a summary line; exit code 1 on any mismatch
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from lidar_slam_amd import _lib                                             # noqa: E402
+from lidar_slam_amd._lib import check, lib, ptr                            # noqa: E402
+from lidar_slam_amd.batch import icp_batch, pack_clouds                    # noqa: E402
+from oracle import c_oracle                                                 # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+
+
+def problem(dim):
+    m = int(rng.choice([rng.integers(4, 40), rng.integers(40, 900), rng.integers(900, 5000)]))
+    n = int(rng.choice([rng.integers(4, 40), rng.integers(40, 900), rng.integers(900, 5000)]))
+    spread = float(rng.choice([0.5, 3.0, 20.0]))
+    tgt = rng.normal(size=(m, dim)) * spread
+    kind = rng.integers(0, 4)
+    if kind == 0:                                   # points on a grid: many exact distance ties
+        tgt = np.round(tgt / (0.05 * spread)) * (0.05 * spread)
+    elif kind == 1 and m > 8:                       # duplicated targets: the lowest index must win
+        tgt[m // 2: m // 2 + m // 8] = tgt[: m // 8]
+    th = rng.uniform(-0.2, 0.2)
+    R = np.eye(dim)
+    R[:2, :2] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]
+    src = (tgt[rng.integers(0, m, n)] - rng.normal(0, 0.05 * spread, dim)) @ R + rng.normal(0, 0.01 * spread, (n, dim))
+    return src, tgt
+
+
+def same(tag, T, e, it, corr, oracle):
+    To, eo, co, ito = oracle
+    ok = it == ito and np.array_equal(corr, co) and np.abs(T - To).max() < 1e-9 and abs(e - eo) <= 1e-9 * abs(eo) + 1e-18
+    if not ok:
+        print("MISMATCH", tag, "iterations", it, ito, "corr equal", np.array_equal(corr, co), "dT", np.abs(T - To).max(), "err", e, eo)
+    return ok
+
+
+t_end, rounds, problems, bad = time.time() + budget, 0, 0, 0
+while time.time() < t_end:
+    dim = int(rng.choice([2, 3]))
+    probs = [problem(dim) for _ in range(24)]
+    flat_s, so = pack_clouds([p[0] for p in probs])
+    flat_t, to = pack_clouds([p[1] for p in probs])
+    init = np.tile(np.eye(4), (len(probs), 1, 1))
+    oracles = [c_oracle.run_icp(s, t, np.eye(4), epsilon=1e-12, max_iters=12, recipe="device") for s, t in probs]
+    for prune in (False, True):
+        r = icp_batch(flat_s, so, flat_t, to, init, epsilon=1e-12, max_iters=12, return_correspondences=True, prune=prune)
+        for k, o in enumerate(oracles):
+            bad += not same(f"batch prune={prune} dim={dim} n={probs[k][0].shape[0]} m={probs[k][1].shape[0]}", r.T[k], r.error[k],
+                            r.iterations[k], r.correspondences[so[k]:so[k + 1]], o)
+    for k, (s, t) in enumerate(probs[:6]):          # the same problems on the whole-chip path (fused below 8192 points)
+        for prune in (0, _lib.ICP_PRUNE):
+            s32, t32 = np.ascontiguousarray(s, np.float32), np.ascontiguousarray(t, np.float32)
+            T = np.empty((4, 4)); e = np.empty(1); it = np.empty(1, np.int32); corr = np.empty(s.shape[0], np.int32)
+            check(lib().lslam_icp_large(ptr(s32), s.shape[0], ptr(t32), t.shape[0], dim, ptr(np.eye(4)), 1e-12, 1e-4, 12, prune,
+                                        ptr(T), ptr(e), ptr(it), ptr(corr), 0))
+            bad += not same(f"whole-chip prune={prune != 0} dim={dim} n={s.shape[0]} m={t.shape[0]}", T, e[0], it[0], corr, oracles[k])
+    rounds += 1; problems += len(probs)
+print(f"soak: {rounds} rounds, {problems} problems x (all-pairs, pruned) + {6 * rounds} x whole-chip (both): {bad} mismatches")
+sys.exit(1 if bad else 0)
