@@ -68,5 +68,6 @@ while time.time() < t_end:
                                         ptr(T), ptr(e), ptr(it), ptr(corr), 0))
             bad += not same(f"whole-chip prune={prune != 0} dim={dim} n={s.shape[0]} m={t.shape[0]}", T, e[0], it[0], corr, oracles[k])
     rounds += 1; problems += len(probs)
+    print(f"round {rounds}: {problems} problems so far, {bad} mismatches", flush=True)   # a silent long run is taken to be hung
 print(f"soak: {rounds} rounds, {problems} problems x (all-pairs, pruned) + {6 * rounds} x whole-chip (both): {bad} mismatches")
 sys.exit(1 if bad else 0)
