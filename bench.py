@@ -84,6 +84,17 @@ def make_c4_on_device(torch, S, P, seed, device):
             off, init.contiguous(), (th, t))
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline_icp(src, tgt, init, P, n_pairs, iters):
     """The oracle's KDTree port of modules/icp.py (same algorithm and complexity as the reference),
     one process — the reference's real behaviour — on the first n_pairs of the workload."""
@@ -253,7 +264,7 @@ def main():
             vall, cores = cpu_baseline_all_cores(h_src, h_tgt, h_init, P, n, I)
             result["cpu_baseline"] = {"value": v, "unit": "iterations/s", "cores": 1, "kind": "port",
                                       "sample": f"first {n} of the {S} pairs, {I} forced iterations each, oracle KDTree port of modules/icp.py, {secs:.1f} s",
-                                      "all_cores_value": vall, "all_cores": cores}
+                                      "all_cores_value": vall, "all_cores": cores, "cpu_model": _cpu_model()}
     else:
         result = other_config(a.workload, a, torch, device, stream, timed=True)
 
