@@ -384,10 +384,10 @@ int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64
   sa.state = ws.state; sa.partials = ws.partials; sa.rows = rows; sa.flags = flags;
   sa.epsilon = epsilon; sa.stopping_thresh = stopping_thresh; sa.max_iters = max_iters;
 
-  // At most max_iters + 1 iterations run (icp.py:174).  Iterations are enqueued in groups (poll_every, then twice
-  // as many each time, up to 32) and the state is read back after each group; the NEXT group is already in the
-  // queue when the host waits for a read-back, so the GPU never idles on a poll.  Launches past convergence return
-  // at once on the `done` flag.
+  // At most max_iters + 1 iterations run (icp.py:174).  Iterations are enqueued in groups of poll_every and the
+  // state is read back after each group; from the second group on the NEXT group is already in the queue when the
+  // host waits for a read-back, so the GPU never idles on a poll.  Launches past convergence return at once on the
+  // `done` flag (≈ 3 µs each: a group of 8 queued in vain costs about what one idle poll would).
   const int64_t cap = (int64_t)max_iters + 1;
   int64_t launched = 0;
   auto enqueue_group = [&](int count, int slot) -> int {
@@ -423,13 +423,11 @@ int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64
     hs = ws.h_back[slot];
     if (hs->done || (!ahead && launched >= cap)) break;
     if (!ahead) {                                           // first poll said "not yet": queue the next group now …
-      group = group * 2 > 32 ? (group > 32 ? group : 32) : group * 2;
       if ((rc = enqueue_group(group, slot ^ 1)) != LSLAM_OK) return rc;
     }
     slot ^= 1;                                              // … that group is what we wait for next,
     ahead = launched < cap;
     if (ahead) {                                            // and one more goes behind it
-      group = group * 2 > 32 ? (group > 32 ? group : 32) : group * 2;
       if ((rc = enqueue_group(group, slot ^ 1)) != LSLAM_OK) return rc;
     }
   }
