@@ -20,18 +20,49 @@ class IcpBatchResult:
 class PackedScans(list):
     """A list of (n_i, d) arrays that are consecutive row slices of ONE packed array (``flat``,
     ``off``).  Behaves exactly like the plain list the reference's pre-processing returns; the
-    batched entry points recognise it and skip re-packing 5 000 small arrays in the interpreter."""
+    batched entry points recognise it and skip re-packing 5 000 small arrays in the interpreter.
+
+    The packed form is only a cache of the list: any mutation of the list (item assignment, ``sort``,
+    ``reverse``, ``append`` …) drops it, so an edited list is honoured like a plain one (re-packed).
+    Writing INTO an element (``z[i][:] = …``) writes into ``flat``: the elements are views."""
 
     def __init__(self, flat, off):
         super().__init__(flat[off[k]:off[k + 1]] for k in range(off.shape[0] - 1))
         self.flat = flat
         self.off = off
 
+    def packed(self):
+        """(flat, off) while the list still is the row slices of ``flat`` it was built from, else None"""
+        if self.flat is None or len(self) != self.off.shape[0] - 1:
+            return None
+        return self.flat, self.off
+
+    def _drop(self):
+        self.flat = None
+        self.off = None
+
+
+def _invalidating(name):
+    plain = getattr(list, name)
+
+    def method(self, *a, **k):
+        self._drop()
+        return plain(self, *a, **k)
+    method.__name__ = name
+    return method
+
+
+for _name in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "extend", "insert", "pop", "remove",
+              "clear", "sort", "reverse"):
+    setattr(PackedScans, _name, _invalidating(_name))
+
 
 def pack_clouds(clouds):
     """list of (n_i, d) arrays -> (float32 (Σn_i, d) C-contiguous, int64 offsets (len+1,))"""
-    if isinstance(clouds, PackedScans) and len(clouds) == clouds.off.shape[0] - 1:
-        return np.ascontiguousarray(clouds.flat, dtype=np.float32), clouds.off
+    if isinstance(clouds, PackedScans):
+        packed = clouds.packed()
+        if packed is not None:
+            return np.ascontiguousarray(packed[0], dtype=np.float32), packed[1]
     d = clouds[0].shape[1] if len(clouds) else 2
     off = np.zeros(len(clouds) + 1, dtype=np.int64)
     off[1:] = np.cumsum([c.shape[0] for c in clouds])

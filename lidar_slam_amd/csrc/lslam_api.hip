@@ -99,6 +99,34 @@ static IcpBatchTuning tuning_from_env() {
   return t;
 }
 
+// A thread's device workspaces (Morton-sorted copies, key rows, iteration state, read-back slots) are reused by its
+// next call.  Calls on ONE stream are ordered by the stream itself; a call on a different stream first waits for
+// the event recorded when the previous call's last work was enqueued (the whole-chip driver returns while a
+// queued-ahead group may still be pending).
+struct WsFence {
+  hipEvent_t ev = nullptr;
+  hipStream_t last = nullptr;
+  int device = -1;
+  bool armed = false;
+  int enter(hipStream_t st) {
+    int dev = 0;
+    LSLAM_HIP_TRY(hipGetDevice(&dev));
+    if (dev != device) {                                     // workspaces of another device are rebuilt (hipFree synchronises)
+      if (ev) (void)hipEventDestroy(ev);
+      ev = nullptr; armed = false; device = dev;
+      LSLAM_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    if (armed && last != st) LSLAM_HIP_TRY(hipStreamWaitEvent(st, ev, 0));
+    return LSLAM_OK;
+  }
+  int leave(hipStream_t st) {
+    LSLAM_HIP_TRY(hipEventRecord(ev, st));
+    last = st; armed = true;
+    return LSLAM_OK;
+  }
+};
+static WsFence& ws_fence() { static thread_local WsFence f; return f; }
+
 }  // namespace lslam
 
 using namespace lslam;
@@ -134,12 +162,11 @@ int lslam_valu_probe(int device, double* out_lane_ops_per_s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-int lslam_icp_batch_dev(const float* d_src, const int64_t* d_src_off, const float* d_tgt,
-                        const int64_t* d_tgt_off, int dim, const double* d_init_T, int32_t S,
-                        int64_t max_src_n, int64_t max_tgt_n, double epsilon, double stopping_thresh,
-                        int32_t max_iters, uint32_t flags, double* d_out_T, double* d_out_err,
-                        int32_t* d_out_iters, int32_t* d_out_corr, void* stream) {
-  clear_error();
+static int icp_batch_dev_impl(const float* d_src, const int64_t* d_src_off, const float* d_tgt,
+                              const int64_t* d_tgt_off, int dim, const double* d_init_T, int32_t S,
+                              int64_t max_src_n, int64_t max_tgt_n, double epsilon, double stopping_thresh,
+                              int32_t max_iters, uint32_t flags, double* d_out_T, double* d_out_err,
+                              int32_t* d_out_iters, int32_t* d_out_corr, void* stream) {
   if (dim != 2 && dim != 3) return fail(LSLAM_ERR_BAD_ARG, "dim must be 2 or 3, got %d", dim);
   if (S < 0) return fail(LSLAM_ERR_BAD_ARG, "negative batch size");
   if (S == 0) return LSLAM_OK;
@@ -154,13 +181,13 @@ int lslam_icp_batch_dev(const float* d_src, const int64_t* d_src_off, const floa
   bool prune = (flags & kFlagPrune) != 0;
   if (const char* e = getenv("LSLAM_ICP_PRUNE")) prune = atoi(e) != 0;
   if (prune && icp_pruned_supported(dim, max_src_n, max_tgt_n)) {
-    // sorted copies: S x max points is an upper bound of the packed sizes (the offsets live on the device)
+    // sorted copies in pair-local slots of S x max points (the offsets live on the device and may start anywhere)
     static thread_local PruneScratch sc{};
     static thread_local size_t cap_src = 0, cap_tgt = 0;
     static thread_local int sc_dev = -1;
     int dev = 0;
     LSLAM_HIP_TRY(hipGetDevice(&dev));
-    const size_t need_src = ((size_t)S + 1) * (size_t)max_src_n, need_tgt = ((size_t)S + 1) * (size_t)max_tgt_n;   // +1: a scan sequence shifts one of the offset arrays by a scan
+    const size_t need_src = (size_t)S * (size_t)max_src_n, need_tgt = (size_t)S * (size_t)max_tgt_n;   // one slot per problem
     if (dev != sc_dev || need_src > cap_src || need_tgt > cap_tgt) {
       LSLAM_HIP_TRY(hipDeviceSynchronize());                 // earlier launches may still read the old buffers
       if (sc.src_sorted) (void)hipFree(sc.src_sorted);
@@ -174,11 +201,26 @@ int lslam_icp_batch_dev(const float* d_src, const int64_t* d_src_off, const floa
       LSLAM_HIP_TRY(hipMalloc(&sc.tgt_index, sizeof(uint16_t) * need_tgt));
       cap_src = need_src; cap_tgt = need_tgt;
     }
+    sc.src_stride = max_src_n; sc.tgt_stride = max_tgt_n;
     LSLAM_HIP_TRY(launch_icp_pruned(a, sc, S, max_src_n, max_tgt_n, static_cast<hipStream_t>(stream)));
     return LSLAM_OK;
   }
   LSLAM_HIP_TRY(launch_icp_batch(a, dim, S, max_src_n, max_tgt_n, tuning_from_env(), static_cast<hipStream_t>(stream)));
   return LSLAM_OK;
+}
+
+int lslam_icp_batch_dev(const float* d_src, const int64_t* d_src_off, const float* d_tgt,
+                        const int64_t* d_tgt_off, int dim, const double* d_init_T, int32_t S,
+                        int64_t max_src_n, int64_t max_tgt_n, double epsilon, double stopping_thresh,
+                        int32_t max_iters, uint32_t flags, double* d_out_T, double* d_out_err,
+                        int32_t* d_out_iters, int32_t* d_out_corr, void* stream) {
+  clear_error();
+  int rc = ws_fence().enter(static_cast<hipStream_t>(stream));
+  if (rc != LSLAM_OK) return rc;
+  rc = icp_batch_dev_impl(d_src, d_src_off, d_tgt, d_tgt_off, dim, d_init_T, S, max_src_n, max_tgt_n, epsilon,
+                          stopping_thresh, max_iters, flags, d_out_T, d_out_err, d_out_iters, d_out_corr, stream);
+  const int rc2 = ws_fence().leave(static_cast<hipStream_t>(stream));
+  return rc != LSLAM_OK ? rc : rc2;
 }
 
 int lslam_icp_batch(const float* src, const int64_t* src_off, const float* tgt, const int64_t* tgt_off,
@@ -332,11 +374,10 @@ LpHolder& lp_holder() { static thread_local LpHolder h; return h; }
 }  // namespace
 }  // extern "C++"
 
-int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64_t m, int dim,
-                        const double* init_T, double epsilon, double stopping_thresh, int32_t max_iters,
-                        uint32_t flags, int32_t poll_every, double* out_T, double* out_err,
-                        int32_t* out_iters, int32_t* d_out_corr, void* stream) {
-  clear_error();
+static int icp_large_dev_impl(const float* d_src, int64_t n, const float* d_tgt, int64_t m, int dim,
+                              const double* init_T, double epsilon, double stopping_thresh, int32_t max_iters,
+                              uint32_t flags, int32_t poll_every, double* out_T, double* out_err,
+                              int32_t* out_iters, int32_t* d_out_corr, void* stream) {
   if (dim != 2 && dim != 3) return fail(LSLAM_ERR_BAD_ARG, "dim must be 2 or 3, got %d", dim);
   if (!d_src || !d_tgt || !init_T || !out_T || !out_err || !out_iters) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
   if (n <= 0) return fail(LSLAM_ERR_BAD_ARG, "empty source cloud");
@@ -437,9 +478,21 @@ int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64
   return LSLAM_OK;
 }
 
-int lslam_nn_dev(const float* d_src, int64_t n, const float* d_tgt, int64_t m, int dim, const double* T,
-                 int32_t* d_out_idx, float* d_out_d2, void* stream) {
+int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64_t m, int dim,
+                        const double* init_T, double epsilon, double stopping_thresh, int32_t max_iters,
+                        uint32_t flags, int32_t poll_every, double* out_T, double* out_err,
+                        int32_t* out_iters, int32_t* d_out_corr, void* stream) {
   clear_error();
+  int rc = ws_fence().enter(static_cast<hipStream_t>(stream));
+  if (rc != LSLAM_OK) return rc;
+  rc = icp_large_dev_impl(d_src, n, d_tgt, m, dim, init_T, epsilon, stopping_thresh, max_iters, flags, poll_every,
+                          out_T, out_err, out_iters, d_out_corr, stream);
+  const int rc2 = ws_fence().leave(static_cast<hipStream_t>(stream));
+  return rc != LSLAM_OK ? rc : rc2;
+}
+
+static int nn_dev_impl(const float* d_src, int64_t n, const float* d_tgt, int64_t m, int dim, const double* T,
+                       int32_t* d_out_idx, float* d_out_d2, void* stream) {
   if (dim != 2 && dim != 3) return fail(LSLAM_ERR_BAD_ARG, "dim must be 2 or 3, got %d", dim);
   if (n < 0) return fail(LSLAM_ERR_BAD_ARG, "negative source size");
   if (n == 0) return LSLAM_OK;
@@ -460,6 +513,16 @@ int lslam_nn_dev(const float* d_src, int64_t n, const float* d_tgt, int64_t m, i
   LSLAM_HIP_TRY(launch_nn(na, dim, geo, st));
   LSLAM_HIP_TRY(launch_nn_finalize(ws.keys, n, geo.splits, d_out_idx, d_out_d2, st));
   return LSLAM_OK;
+}
+
+int lslam_nn_dev(const float* d_src, int64_t n, const float* d_tgt, int64_t m, int dim, const double* T,
+                 int32_t* d_out_idx, float* d_out_d2, void* stream) {
+  clear_error();
+  int rc = ws_fence().enter(static_cast<hipStream_t>(stream));
+  if (rc != LSLAM_OK) return rc;
+  rc = nn_dev_impl(d_src, n, d_tgt, m, dim, T, d_out_idx, d_out_d2, stream);
+  const int rc2 = ws_fence().leave(static_cast<hipStream_t>(stream));
+  return rc != LSLAM_OK ? rc : rc2;
 }
 
 // host-pointer wrappers of the two entry points above

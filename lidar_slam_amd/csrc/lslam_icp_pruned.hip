@@ -75,6 +75,9 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2) {
   const int n = (int)(a.src_off[pair + 1] - s0), m = (int)(a.tgt_off[pair + 1] - t0);
   const float2* src = reinterpret_cast<const float2*>(a.src) + s0;
   const float2* tgt = reinterpret_cast<const float2*>(a.tgt) + t0;
+  // the sorted copies live in pair-local slots of the scratch (slot = pair · stride): the caller's offsets may
+  // start anywhere in a larger packed buffer, the scratch is sized for this batch only
+  const int64_t ss = (int64_t)pair * sc.src_stride, ts = (int64_t)pair * sc.tgt_stride;
 
   // bounding box of the target
   float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
@@ -110,8 +113,8 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2) {
   bitonic_sort(keys, len_pow2);
   for (int j = tid; j < m; j += kSortThreads) {
     const unsigned o = keys[j] & 8191u;
-    sc.tgt_sorted[t0 + j] = tgt[o];
-    sc.tgt_index[t0 + j] = (uint16_t)o;
+    sc.tgt_sorted[ts + j] = tgt[o];
+    sc.tgt_index[ts + j] = (uint16_t)o;
   }
   __syncthreads();
   // ---- source, placed by its initial transform into the target's grid ----
@@ -128,8 +131,8 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2) {
   bitonic_sort(keys, len_pow2);
   for (int i = tid; i < n; i += kSortThreads) {
     const unsigned o = keys[i] & 8191u;
-    sc.src_sorted[s0 + i] = src[o];
-    sc.src_index[s0 + i] = (uint16_t)o;
+    sc.src_sorted[ss + i] = src[o];
+    sc.src_index[ss + i] = (uint16_t)o;
   }
 }
 
@@ -153,15 +156,16 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int64_t s0 = args.src_off[pair], t0 = args.tgt_off[pair];
   const int n = (int)(args.src_off[pair + 1] - s0), m = (int)(args.tgt_off[pair + 1] - t0);
-  const float2* __restrict__ ssrc = sc.src_sorted + s0;        // Morton-sorted sources (L2-resident)
+  const int64_t ss = (int64_t)pair * sc.src_stride, ts = (int64_t)pair * sc.tgt_stride;   // pair-local scratch slots
+  const float2* __restrict__ ssrc = sc.src_sorted + ss;        // Morton-sorted sources (L2-resident)
   const bool box = (args.flags & kFlagNormalize) != 0;
   const int nchunks = (m + CHUNK - 1) / CHUNK;
   const int nsuper = (nchunks + SUPER - 1) / SUPER;
 
   if (tid < 16) sh_T[tid] = args.init_T[(int64_t)16 * pair + tid];
   for (int j = tid; j < nchunks * CHUNK; j += blockDim.x) {
-    tile[j] = (j < m) ? sc.tgt_sorted[t0 + j] : make_float2(kFar, kFar);
-    tidx[j] = (j < m) ? sc.tgt_index[t0 + j] : (uint16_t)0xffff;
+    tile[j] = (j < m) ? sc.tgt_sorted[ts + j] : make_float2(kFar, kFar);
+    tidx[j] = (j < m) ? sc.tgt_index[ts + j] : (uint16_t)0xffff;
   }
   for (int i = tid; i < n; i += blockDim.x) sh_prev[i] = 0xffff;
   __syncthreads();
@@ -350,7 +354,7 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
           pd[1] = T[1][0] * (double)v.x + T[1][1] * (double)v.y + T[1][3];
           qd[0] = (double)q.x; qd[1] = (double)q.y;
           acc.add(pd, qd, box);
-          if (args.out_corr) args.out_corr[s0 + sc.src_index[s0 + i]] = tidx[ps];
+          if (args.out_corr) args.out_corr[s0 + sc.src_index[ss + i]] = tidx[ps];
         }
       }
     }

@@ -55,9 +55,10 @@ struct IcpBatchTuning {
 // ---- exact chunk pruning (lslam_icp_pruned.hip) ----------------------------------------------------
 constexpr uint32_t kFlagPrune = 2u;        // == LSLAM_ICP_PRUNE
 constexpr int kPruneMaxPoints = 4096;      // per cloud: both sorted clouds + boxes + indices must fit LDS
-struct PruneScratch {                      // Morton-sorted copies, laid out like the original offsets
+struct PruneScratch {                      // Morton-sorted copies: problem k owns slot [k·stride, (k+1)·stride)
   float2* src_sorted; uint16_t* src_index;
   float2* tgt_sorted; uint16_t* tgt_index;
+  int64_t src_stride, tgt_stride;          // = max_src_n, max_tgt_n of the batch
 };
 struct PruneLayout { uint32_t aabb_off, aabb2_off, tidx_off, prev_off, red_off; };
 bool icp_pruned_supported(int dim, int64_t max_src_n, int64_t max_tgt_n);

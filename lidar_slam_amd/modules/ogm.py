@@ -94,8 +94,9 @@ class OccupancyGridMap:
             check(lib().lslam_ogm_binarize(self._handle, ptr(out)))
             self.grid_map = out
             return
-        if isinstance(meas, PackedScans) and len(meas) == K and meas.flat.dtype == np.float64:
-            flat, off = np.ascontiguousarray(meas.flat), meas.off          # already packed: no copies
+        packed = meas.packed() if isinstance(meas, PackedScans) and len(meas) == K else None
+        if packed is not None and packed[0].dtype == np.float64 and packed[0].ndim == 2 and packed[0].shape[1] == 2:
+            flat, off = np.ascontiguousarray(packed[0]), packed[1]        # already packed: no copies
         else:
             off = np.zeros(K + 1, dtype=np.int64)
             scans = [np.asarray(meas[i], dtype=np.float64).reshape(-1, 2) for i in range(K)]

@@ -476,3 +476,24 @@ def test_module_switch_for_pruning_keeps_run_icp_results(icp, monkeypatch):
     np.testing.assert_allclose(got[0], ref[0], atol=1e-11)
     np.testing.assert_allclose(got[1], ref[1], rtol=1e-10)
     close_to_reference(got[0], g["T"][1])
+
+
+@pytest.mark.parametrize("prune", [False, True])
+def test_sub_range_of_a_packed_buffer(icp, prune):
+    """offsets that start in the middle of a larger packed buffer (off[0] > 0): the pruned path keeps its sorted
+    copies in batch-local scratch, so a sub-range must give the full batch's answers and touch nothing else"""
+    from lidar_slam_amd.batch import icp_batch, pack_clouds
+    rng = np.random.default_rng(321)
+    sizes = [(900, 1100), (4096, 4096), (300, 2000), (1081, 1081), (2000, 64), (64, 3000), (1500, 1500), (700, 4096),
+             (4096, 100), (1200, 1000)]
+    ss, ts = zip(*[_random_problem(rng, 2, n, m, spread=rng.uniform(1.0, 15.0)) for n, m in sizes])
+    fs, so = pack_clouds(list(ss))
+    ft, to = pack_clouds(list(ts))
+    I = np.tile(np.eye(4), (len(sizes), 1, 1))
+    kw = dict(epsilon=1e-12, max_iters=8, return_correspondences=True)
+    full = icp_batch(fs, so, ft, to, I, **kw)
+    for lo, hi in ((6, 10), (3, 4), (9, 10)):
+        sub = icp_batch(fs, so[lo:hi + 1], ft, to[lo:hi + 1], I[lo:hi], prune=prune, **kw)
+        np.testing.assert_array_equal(sub.iterations, full.iterations[lo:hi])
+        np.testing.assert_array_equal(sub.correspondences[so[lo]:so[hi]], full.correspondences[so[lo]:so[hi]])
+        np.testing.assert_allclose(sub.T, full.T[lo:hi], atol=1e-10)

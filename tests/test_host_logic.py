@@ -1,0 +1,55 @@
+"""Host-side logic that needs no GPU: packing of scan lists (PackedScans keeps the semantics of the plain
+list the reference's pre-processing returns, localization.py:252-307 / main.py:84-87)."""
+
+import numpy as np
+
+from lidar_slam_amd.batch import PackedScans, pack_clouds
+
+
+def _scans(rng, sizes):
+    off = np.zeros(len(sizes) + 1, np.int64)
+    off[1:] = np.cumsum(sizes)
+    return PackedScans(rng.normal(size=(int(off[-1]), 2)), off)
+
+
+def test_packed_scans_is_a_list_of_views_and_packs_without_copying_element_by_element():
+    rng = np.random.default_rng(0)
+    z = _scans(rng, [5, 0, 7, 3])
+    assert isinstance(z, list) and len(z) == 4 and [s.shape for s in z] == [(5, 2), (0, 2), (7, 2), (3, 2)]
+    flat, off = pack_clouds(z)
+    assert flat.dtype == np.float32 and off is z.off
+    np.testing.assert_array_equal(flat, z.flat.astype(np.float32))
+    # writing INTO an element writes into the packed array (elements are views)
+    z[2][:] = 1.5
+    flat2, _ = pack_clouds(z)
+    assert (flat2[off[2]:off[3]] == 1.5).all()
+
+
+def test_mutating_the_list_is_honoured_like_a_plain_list():
+    rng = np.random.default_rng(1)
+    mutations = {
+        "setitem": lambda z: z.__setitem__(1, z[1][::2]),
+        "delitem": lambda z: z.__delitem__(0),
+        "reverse": lambda z: z.reverse(),
+        "sort": lambda z: z.sort(key=lambda a: a.shape[0]),
+        "append": lambda z: z.append(np.ones((2, 2))),
+        "insert": lambda z: z.insert(1, np.ones((2, 2))),
+        "pop": lambda z: z.pop(),
+        "extend": lambda z: z.extend([np.zeros((1, 2))]),
+        "iadd": lambda z: z.__iadd__([np.zeros((1, 2))]),
+        "slice": lambda z: z.__setitem__(slice(0, 2), [z[1], z[0]]),
+    }
+    for name, edit in mutations.items():
+        z = _scans(rng, [4, 6, 3, 5])
+        edit(z)
+        assert z.packed() is None, name
+        flat, off = pack_clouds(z)                                   # re-packed from the list as it is now
+        want = np.concatenate([np.asarray(s) for s in z], axis=0).astype(np.float32)
+        np.testing.assert_array_equal(flat, want, err_msg=name)
+        assert off.tolist() == np.concatenate(([0], np.cumsum([s.shape[0] for s in z]))).tolist(), name
+
+
+def test_pack_clouds_rejects_mixed_dimensions():
+    import pytest
+    with pytest.raises(ValueError):
+        pack_clouds([np.zeros((3, 2)), np.zeros((3, 3))])
