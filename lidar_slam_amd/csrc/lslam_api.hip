@@ -96,6 +96,7 @@ static IcpBatchTuning tuning_from_env() {
   if (const char* e = getenv("LSLAM_ICP_TILE_POINTS")) t.tile_points = atoi(e);
   if (const char* e = getenv("LSLAM_ICP_VARIANT")) t.variant = atoi(e);
   if (const char* e = getenv("LSLAM_ICP_SRC_IN_LDS")) t.src_in_lds = atoi(e);
+  if (const char* e = getenv("LSLAM_ICP_FILTER")) t.filter = atoi(e) != 0 ? 0 : 2;
   return t;
 }
 

@@ -18,6 +18,15 @@
 //     reference's stop rules and publishes T through LDS.
 // HBM traffic per problem: the two clouds once, 16+16 doubles of transforms; everything else is
 // on chip.  The kernel is float32-VALU-issue bound.
+//
+// FILTER build (big clouds, target resident in LDS): the all-pairs sweep runs on the EXPANDED form
+//   g(a, t) = |t|² − 2 a·t  ( = |a − t|² − |a|² )      2 (planar) / 3 (3-D) v_fma per pair
+// with |t|² kept beside the target in LDS.  g is only a filter: its float32 error against the exact
+// direct-difference distance is bounded by E = c·2⁻²⁴·R(R + |a|) (R = largest |t| of the problem), so the
+// exact winner lies in a chunk whose filter minimum is within τ = 2E + 9·2⁻²⁴·d² of the best one.  The sweep
+// keeps the three smallest chunk minima (two with their chunk id); chunks within τ are then re-evaluated
+// with the exact recipe.  If a third chunk is within τ (rare on random clouds; always on lattices or clouds
+// far from the origin) the wave falls back to the exact sweep — results are identical by construction.
 #include <hip/hip_runtime.h>
 
 #include "lslam_device.h"
@@ -109,16 +118,133 @@ __device__ __forceinline__ void sweep_tile(const typename TilePoint<DIM>::type* 
   }
 }
 
-template <int DIM, int P, int CHUNK>
+
+// ---- the all-pairs FILTER sweep (expanded form) -------------------------------------------------
+// na[p] = −2·a[p]; per chunk of FCH targets: the minimum of g, then the update of the three smallest
+// chunk minima b1 ≤ b2 ≤ b3 and the chunk ids of the first two.
+constexpr int kFilterChunk = 32;
+constexpr int kFilterStep = 8;                 // targets per load group
+
+template <int DIM> struct FilterRegs;          // one load group in registers
+template <> struct FilterRegs<2> { float4 v[4], w[2]; };      // 8 × (x, y) + 8 × |t|²
+template <> struct FilterRegs<3> { float4 v[8]; };            // 8 × (x, y, z, |t|²)
+
+template <int DIM>
+__device__ __forceinline__ void filter_load(FilterRegs<DIM>& r, const typename TilePoint<DIM>::type* tile, const float* wt, int step) {
+  if constexpr (DIM == 2) {
+    const float4* t4 = reinterpret_cast<const float4*>(tile) + step * 4;      // two points per 16 B
+    const float4* w4 = reinterpret_cast<const float4*>(wt) + step * 2;        // four |t|² per 16 B
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.v[k] = t4[k];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) r.w[k] = w4[k];
+  } else {
+    const float4* t4 = tile + step * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.v[k] = t4[k];
+  }
+}
+
+template <int DIM, int P>
+__device__ __forceinline__ void filter_eval(const FilterRegs<DIM>& r, const float (&na)[P][DIM], float (&m)[P]) {
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    if constexpr (DIM == 2) {
+      const float nx = na[p][0], ny = na[p][1];
+      const float g0 = __builtin_fmaf(r.v[0].x, nx, __builtin_fmaf(r.v[0].y, ny, r.w[0].x));
+      const float g1 = __builtin_fmaf(r.v[0].z, nx, __builtin_fmaf(r.v[0].w, ny, r.w[0].y));
+      const float g2 = __builtin_fmaf(r.v[1].x, nx, __builtin_fmaf(r.v[1].y, ny, r.w[0].z));
+      const float g3 = __builtin_fmaf(r.v[1].z, nx, __builtin_fmaf(r.v[1].w, ny, r.w[0].w));
+      const float g4 = __builtin_fmaf(r.v[2].x, nx, __builtin_fmaf(r.v[2].y, ny, r.w[1].x));
+      const float g5 = __builtin_fmaf(r.v[2].z, nx, __builtin_fmaf(r.v[2].w, ny, r.w[1].y));
+      const float g6 = __builtin_fmaf(r.v[3].x, nx, __builtin_fmaf(r.v[3].y, ny, r.w[1].z));
+      const float g7 = __builtin_fmaf(r.v[3].z, nx, __builtin_fmaf(r.v[3].w, ny, r.w[1].w));
+      float mm = fminf(fminf(g0, g1), m[p]);
+      mm = fminf(fminf(g2, g3), mm);
+      mm = fminf(fminf(g4, g5), mm);
+      m[p] = fminf(fminf(g6, g7), mm);
+    } else {
+      const float nx = na[p][0], ny = na[p][1], nz = na[p][2];
+      float mm = m[p];
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        const float g0 = __builtin_fmaf(r.v[k].x, nx, __builtin_fmaf(r.v[k].y, ny, __builtin_fmaf(r.v[k].z, nz, r.v[k].w)));
+        const float g1 = __builtin_fmaf(r.v[k + 1].x, nx, __builtin_fmaf(r.v[k + 1].y, ny, __builtin_fmaf(r.v[k + 1].z, nz, r.v[k + 1].w)));
+        mm = fminf(fminf(g0, g1), mm);
+      }
+      m[p] = mm;
+    }
+  }
+}
+
+// na[p] = −2·a[p]; per chunk of kFilterChunk targets: the minimum of g, then the update of the three smallest
+// chunk minima b1 ≤ b2 ≤ b3 and the chunk ids of the first two.  (Issuing a group's loads one group ahead of
+// its use — two register buffers held apart with scheduling barriers — was measured: no gain, 24 more VGPRs.)
+template <int DIM, int P>
+__device__ __forceinline__ void filter_sweep(const typename TilePoint<DIM>::type* tile, const float* wt, int nchunks,
+                                             const float (&na)[P][DIM], float (&b1)[P], float (&b2)[P], float (&b3)[P],
+                                             int (&i1)[P], int (&i2)[P]) {
+  constexpr int kGroups = kFilterChunk / kFilterStep;          // 4 load groups per chunk
+  for (int c = 0; c < nchunks; ++c) {
+    float m[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) m[p] = INFINITY;
+    // NOT unrolled: the compiler would hoist all 24 loads of a chunk to its top and spill
+#pragma unroll 1
+    for (int h = 0; h < kGroups; ++h) {
+      FilterRegs<DIM> A;
+      filter_load<DIM>(A, tile, wt, c * kGroups + h);
+      filter_eval<DIM, P>(A, na, m);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float mc = m[p];
+      // selects, not branches (the conditions are data-dependent per lane)
+      const bool lt1 = __builtin_unpredictable(mc < b1[p]), lt2 = __builtin_unpredictable(mc < b2[p]);
+      b3[p] = __builtin_amdgcn_fmed3f(b2[p], b3[p], mc);     // b2 ≤ b3 holds: the median is the new third smallest
+      b2[p] = __builtin_amdgcn_fmed3f(b1[p], b2[p], mc);
+      b1[p] = lt1 ? mc : b1[p];
+      const int i2n = lt2 ? c : i2[p];
+      i2[p] = lt1 ? i1[p] : i2n;
+      i1[p] = lt1 ? c : i1[p];
+    }
+  }
+}
+
+// exact distances of the targets of one filter chunk: minimum of the 64-bit key (distance bits, index) — distances
+// are non-negative floats, whose order is the order of their bit patterns, so one unsigned compare is the
+// lexicographic (distance, lowest index) rule
+template <int DIM>
+__device__ __forceinline__ void exact_chunk(const typename TilePoint<DIM>::type* tile, int chunk, int lane, const float (&a)[DIM],
+                                            unsigned long long& best) {
+  using TP = typename TilePoint<DIM>::type;
+  const int j0 = chunk * kFilterChunk;
+  // opaque copy of the lane id: otherwise the 32 rotated offsets are hoisted out of the ICP loop as 32 live
+  // registers (spilled, then reloaded from scratch at every use)
+  asm volatile("" : "+v"(lane));
+#pragma unroll 8
+  for (int kk = 0; kk < kFilterChunk; ++kk) {
+    const int j = j0 + ((kk + lane) & (kFilterChunk - 1));   // rotated start: every chunk begins on the same banks
+    const TP v = tile[j];
+    float d;
+    if constexpr (DIM == 2) d = dist2(a[0], a[1], v.x, v.y);
+    else d = dist2(a[0], a[1], a[2], v.x, v.y, v.z);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
+    best = key < best ? key : best;
+  }
+}
+
+template <int DIM, int P, int CHUNK, bool FILTER>
 __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
   using TP = typename TilePoint<DIM>::type;
   constexpr int kAcc = AccLayout<DIM>::kTotal;
   extern __shared__ __align__(16) unsigned char smem[];
   TP* tile = reinterpret_cast<TP*>(smem);
-  float* sh_src = reinterpret_cast<float*>(smem + args.tile_bytes);           // the source cloud, DIM floats per point
-  double* sh_red = reinterpret_cast<double*>(smem + args.tile_bytes + args.src_bytes);   // [waves][kAcc]
+  float* wtile = reinterpret_cast<float*>(smem + args.tile_bytes);            // |t|² per target (planar FILTER build; 3-D keeps it in .w)
+  float* sh_src = reinterpret_cast<float*>(smem + args.tile_bytes + args.w_bytes);   // the source cloud, DIM floats per point
+  double* sh_red = reinterpret_cast<double*>(smem + args.tile_bytes + args.w_bytes + args.src_bytes);   // [waves][kAcc]
   double* sh_T = sh_red + (size_t)kIcpBatchMaxWaves * kAcc;                   // current transform, 16
-  int* sh_flag = reinterpret_cast<int*>(sh_T + 16);                           // [0] stop
+  int* sh_flag = reinterpret_cast<int*>(sh_T + 16);                           // [0] stop, [1] bits of max |t|² (FILTER)
 
   const int pair = blockIdx.x;
   const int tid = threadIdx.x;
@@ -135,11 +261,14 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
   const bool box = (args.flags & kFlagNormalize) != 0;
 
   if (tid < 16) sh_T[tid] = args.init_T[(int64_t)16 * pair + tid];
+  if (FILTER && tid == 0) sh_flag[1] = 0;
 
-  const int tile_cap = args.tile_points;                       // multiple of CHUNK
+  const int tile_cap = args.tile_points;                       // multiple of CHUNK (and of kFilterChunk in the FILTER build)
   const int ntiles = (m + tile_cap - 1) / tile_cap;
-  const bool resident = (ntiles <= 1);                         // whole target stays in LDS
-  if (resident) stage_tile<DIM>(gtgt, m, ((m + CHUNK - 1) / CHUNK) * CHUNK, tile);
+  const bool resident = FILTER || (ntiles <= 1);               // whole target stays in LDS (the launcher picks the FILTER build only then)
+  constexpr int kPad = FILTER ? kFilterChunk : CHUNK;
+  const int m_padded = ((m + kPad - 1) / kPad) * kPad;
+  if (resident) stage_tile<DIM>(gtgt, m, m_padded, tile);
   // the source cloud is read every iteration (twice): keep it in LDS too when it fits, so that HBM/L2
   // see each cloud exactly once per problem
   const bool src_resident = (size_t)n * DIM * sizeof(float) <= args.src_bytes;
@@ -147,11 +276,32 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
     for (int i = tid; i < n * DIM; i += blockDim.x) sh_src[i] = gsrc[i];
   const float* __restrict__ psrc = src_resident ? sh_src : gsrc;
   __syncthreads();
+  float Rt = 0.f;                                              // ≥ the largest |t| of the problem
+  if constexpr (FILTER) {
+    // |t|² beside every target (+inf on the padding: g = +inf there, the padding coordinates never produce a NaN
+    // because an fma only rounds once); the largest one bounds the filter's rounding error
+    float wmax = 0.f;
+    for (int j = tid; j < m_padded; j += blockDim.x) {
+      const TP v = tile[j];
+      float w;
+      if constexpr (DIM == 2) w = __builtin_fmaf(v.y, v.y, v.x * v.x);
+      else w = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
+      if (j < m) wmax = fmaxf(wmax, w); else w = INFINITY;
+      if constexpr (DIM == 2) wtile[j] = w;
+      else tile[j].w = w;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, kWave));
+    if (lane == 0) atomicMax(&sh_flag[1], __float_as_int(wmax));      // non-negative floats order like their bits
+    __syncthreads();
+    Rt = sqrtf(__int_as_float(sh_flag[1])) * 1.0001f;
+  }
 
   StopState st;
   stop_init(st);
   double err_out = 0.0;
   const int src_per_pass = blockDim.x * P;
+  int f_tries = 0, f_fails = 0;                                // wave-uniform: filter passes attempted / fallen back
 
   // One pass = blockDim·P source points: transform, sweep all targets, fix up the index, add the
   // pair to the float64 moments.  Only the float32 copies of the points live across the sweep;
@@ -181,57 +331,127 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
       }
     }
 
-    // ---- nearest neighbour over all targets --------------------------------------------------
-    float best[P];
-    int bchunk[P];
+    int bi[P];                                               // matched target index and its coordinates
+    float q[P][DIM];
+    bool matched = false;
+
+    // ---- FILTER build: expanded-form sweep, then the exact recipe on the chunks that can hold the winner ----
+    if constexpr (FILTER) {
+      // the filter is dropped for this wave once it fell back in at least half of its attempts (lattices, clouds far
+      // from the origin): from then on the exact sweep runs directly
+      if (resident && wave_live && 2 * f_fails < f_tries + 1) {
+        float b1[P], b2[P], b3[P], na[P][DIM];
+        int i1[P], i2[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) { best[p] = INFINITY; bchunk[p] = 0; }
-    if (resident) {
-      if (wave_live) sweep_tile<DIM, P, CHUNK>(tile, (m + CHUNK - 1) / CHUNK, 0, a, best, bchunk);
-    } else {
-      for (int t = 0; t < ntiles; ++t) {
-        const int first = t * tile_cap;
-        const int cnt = min(tile_cap, m - first);
-        __syncthreads();                                     // previous tile fully consumed
-        stage_tile<DIM>(gtgt + (int64_t)DIM * first, cnt, ((cnt + CHUNK - 1) / CHUNK) * CHUNK, tile);
-        __syncthreads();
-        if (wave_live) sweep_tile<DIM, P, CHUNK>(tile, (cnt + CHUNK - 1) / CHUNK, first / CHUNK, a, best, bchunk);
+        for (int p = 0; p < P; ++p) {
+          b1[p] = b2[p] = b3[p] = INFINITY; i1[p] = 0; i2[p] = 0;
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) na[p][r] = -2.f * a[p][r];
+        }
+        filter_sweep<DIM, P>(tile, wtile, m_padded / kFilterChunk, na, b1, b2, b3, i1, i2);
+        // rounding-error bound of g against the exact distance (see the header comment and DESIGN.md §3.1c)
+        constexpr float kU = 5.97e-8f;                       // > 2⁻²⁴
+        constexpr float kE = (DIM == 2 ? 4.5f : 6.5f) * kU;
+        bool two[P], fall = false;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          float a2;
+          if constexpr (DIM == 2) a2 = __builtin_fmaf(a[p][1], a[p][1], a[p][0] * a[p][0]);
+          else a2 = __builtin_fmaf(a[p][2], a[p][2], __builtin_fmaf(a[p][1], a[p][1], a[p][0] * a[p][0]));
+          const float an = sqrtf(a2) * 1.0001f;
+          const float E = kE * Rt * (Rt + an);
+          const float d2 = fmaxf((b1[p] + a2) * 1.000001f + E + 3.f * kU * a2, 0.f);       // ≥ |a − t|² of the filter's winner
+          const float tau = (2.f * E + 9.f * kU * d2) * 1.001f + 1e-30f;
+          const float lim = b1[p] + tau;
+          const bool own = base + tid * P + p < n;
+          two[p] = !(b2[p] > lim);
+          // a third chunk within the bound, or magnitudes where the filter could overflow: exact sweep instead
+          fall |= own && (!(b3[p] > lim) || !(Rt < 1e15f) || !(an < 1e15f));
+        }
+        f_tries++;
+        if (__any(fall)) {
+          f_fails++;
+        } else {
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            unsigned long long k1 = ~0ull;
+            exact_chunk<DIM>(tile, i1[p], lane, a[p], k1);
+            if (__any(two[p])) {
+              unsigned long long k2 = k1;
+              exact_chunk<DIM>(tile, i2[p], lane, a[p], k2);
+              k1 = two[p] ? k2 : k1;
+            }
+            bi[p] = (int)(unsigned)k1;
+            const TP v = tile[bi[p]];
+            q[p][0] = v.x; q[p][1] = v.y;
+            if constexpr (DIM == 3) q[p][2] = v.z;
+          }
+          matched = true;
+        }
       }
     }
 
-    // ---- fix-up: exact index inside the winning chunk; moments in float64 --------------------
-    if (!wave_live) return;
+    if (!matched) {
+      // ---- nearest neighbour over all targets, exact recipe ----------------------------------------
+      float best[P];
+      int bchunk[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int j0 = bchunk[p] * CHUNK;
-      float bd = INFINITY;
-      int bi = j0;
-      float q[DIM] = {};
-#pragma unroll
-      for (int kk = 0; kk < CHUNK; ++kk) {
-        // every lane starts at a different point of its chunk: all chunks begin on the same LDS
-        // banks, an unrotated gather would be a 32-way bank conflict
-        const int k = (kk + lane) & (CHUNK - 1);
-        const int j = j0 + k;
-        float bx, by, bz = 0.f;
-        if (resident) {
-          const TP v = tile[j];
-          bx = v.x; by = v.y;
-          if constexpr (DIM == 3) bz = v.z;
-        } else {
-          const bool in = j < m;
-          bx = in ? gtgt[(int64_t)DIM * j] : kFar;
-          by = in ? gtgt[(int64_t)DIM * j + 1] : kFar;
-          if constexpr (DIM == 3) bz = in ? gtgt[(int64_t)DIM * j + 2] : kFar;
-        }
-        float d;
-        if constexpr (DIM == 2) d = dist2(a[p][0], a[p][1], bx, by);
-        else d = dist2(a[p][0], a[p][1], a[p][2], bx, by, bz);
-        if (kk == 0 || d < bd || (d == bd && j < bi)) {      // lowest index on ties, whatever the visiting order
-          bd = d; bi = j; q[0] = bx; q[1] = by;
-          if constexpr (DIM == 3) q[2] = bz;
+      for (int p = 0; p < P; ++p) { best[p] = INFINITY; bchunk[p] = 0; }
+      if (resident) {
+        if (wave_live) sweep_tile<DIM, P, CHUNK>(tile, (m + CHUNK - 1) / CHUNK, 0, a, best, bchunk);
+      } else {
+        for (int t = 0; t < ntiles; ++t) {
+          const int first = t * tile_cap;
+          const int cnt = min(tile_cap, m - first);
+          __syncthreads();                                     // previous tile fully consumed
+          stage_tile<DIM>(gtgt + (int64_t)DIM * first, cnt, ((cnt + CHUNK - 1) / CHUNK) * CHUNK, tile);
+          __syncthreads();
+          if (wave_live) sweep_tile<DIM, P, CHUNK>(tile, (cnt + CHUNK - 1) / CHUNK, first / CHUNK, a, best, bchunk);
         }
       }
+
+      // ---- fix-up: exact index inside the winning chunk ----------------------------------------------
+      if (!wave_live) return;
+      int rot = lane;
+      asm volatile("" : "+v"(rot));                          // opaque: keeps the CHUNK rotated offsets from being hoisted out of the ICP loop (and spilled)
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int j0 = bchunk[p] * CHUNK;
+        float bd = INFINITY;
+        bi[p] = j0;
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) q[p][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < CHUNK; ++kk) {
+          // every lane starts at a different point of its chunk: all chunks begin on the same LDS
+          // banks, an unrotated gather would be a 32-way bank conflict
+          const int k = (kk + rot) & (CHUNK - 1);
+          const int j = j0 + k;
+          float bx, by, bz = 0.f;
+          if (resident) {
+            const TP v = tile[j];
+            bx = v.x; by = v.y;
+            if constexpr (DIM == 3) bz = v.z;
+          } else {
+            const bool in = j < m;
+            bx = in ? gtgt[(int64_t)DIM * j] : kFar;
+            by = in ? gtgt[(int64_t)DIM * j + 1] : kFar;
+            if constexpr (DIM == 3) bz = in ? gtgt[(int64_t)DIM * j + 2] : kFar;
+          }
+          float d;
+          if constexpr (DIM == 2) d = dist2(a[p][0], a[p][1], bx, by);
+          else d = dist2(a[p][0], a[p][1], a[p][2], bx, by, bz);
+          if (kk == 0 || d < bd || (d == bd && j < bi[p])) {      // lowest index on ties, whatever the visiting order
+            bd = d; bi[p] = j; q[p][0] = bx; q[p][1] = by;
+            if constexpr (DIM == 3) q[p][2] = bz;
+          }
+        }
+      }
+    }
+
+    // ---- the matched pairs go to the float64 moments -------------------------------------------------
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
       const int i = base + tid * P + p;
       if (i < n) {
         double x, y, z = 0.0;
@@ -247,10 +467,10 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
           double v = T[r][0] * x + T[r][1] * y + T[r][3];
           if constexpr (DIM == 3) v += T[r][2] * z;
           pd[r] = v;
-          qd[r] = (double)q[r];
+          qd[r] = (double)q[p][r];
         }
         acc.add(pd, qd, box);
-        if (args.out_corr) args.out_corr[s0 + i] = bi;
+        if (args.out_corr) args.out_corr[s0 + i] = bi[p];
       }
     }
   };
@@ -330,25 +550,36 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
 template <int DIM, int P>
 __global__ void __launch_bounds__(kIcpBatchMaxThreads)
 icp_batch_kernel(IcpBatchArgs args) {
-  icp_batch_body<DIM, P, IcpChunk<DIM>::value>(args);
+  icp_batch_body<DIM, P, IcpChunk<DIM>::value, false>(args);
+}
+
+// the big build with the expanded-form filter sweep in front of the exact recipe (target resident in LDS)
+template <int DIM, int P>
+__global__ void __launch_bounds__(kIcpBatchMaxThreads)
+icp_batch_filter_kernel(IcpBatchArgs args) {
+  icp_batch_body<DIM, P, IcpChunk<DIM>::value, true>(args);
 }
 
 template <int DIM, int P>
 __global__ void __launch_bounds__(kIcpSmallMaxThreads, 8)
 icp_batch_small_kernel(IcpBatchArgs args) {
-  icp_batch_body<DIM, P, IcpChunkSmall<DIM>::value>(args);
+  icp_batch_body<DIM, P, IcpChunkSmall<DIM>::value, false>(args);
 }
 
 // ---- launch ------------------------------------------------------------------------------------
+enum class Build { kBig, kSmall, kFilter };
+
 template <int DIM, int P>
-static hipError_t launch_one(const IcpBatchArgs& a, int S, int threads, size_t smem, bool small, hipStream_t stream) {
-  const void* fn = small ? reinterpret_cast<const void*>(icp_batch_small_kernel<DIM, P>)
-                         : reinterpret_cast<const void*>(icp_batch_kernel<DIM, P>);
+static hipError_t launch_one(const IcpBatchArgs& a, int S, int threads, size_t smem, Build build, hipStream_t stream) {
+  const void* fn = build == Build::kSmall ? reinterpret_cast<const void*>(icp_batch_small_kernel<DIM, P>)
+                 : build == Build::kFilter ? reinterpret_cast<const void*>(icp_batch_filter_kernel<DIM, P>)
+                                           : reinterpret_cast<const void*>(icp_batch_kernel<DIM, P>);
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
   }
-  if (small) hipLaunchKernelGGL((icp_batch_small_kernel<DIM, P>), dim3(S), dim3(threads), smem, stream, a);
+  if (build == Build::kSmall) hipLaunchKernelGGL((icp_batch_small_kernel<DIM, P>), dim3(S), dim3(threads), smem, stream, a);
+  else if (build == Build::kFilter) hipLaunchKernelGGL((icp_batch_filter_kernel<DIM, P>), dim3(S), dim3(threads), smem, stream, a);
   else hipLaunchKernelGGL((icp_batch_kernel<DIM, P>), dim3(S), dim3(threads), smem, stream, a);
   return hipGetLastError();
 }
@@ -375,26 +606,32 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
   int cap = (dim == 2) ? kIcpTileMaxPlanar : kIcpTileMax3D;
   if (tune.tile_points > 0) cap = tune.tile_points;
   cap = ((cap + 31) / 32) * 32;                              // a multiple of every chunk size
-  int64_t need = ((max_tgt_n + CHUNK - 1) / CHUNK) * CHUNK;
-  if (need < CHUNK) need = CHUNK;
+  // the expanded-form filter needs the whole target in LDS (one tile); it is the default of the big build
+  const bool filter = !small && max_tgt_n <= cap && tune.filter != 2;
+  const int pad = filter ? kFilterChunk : CHUNK;
+  int64_t need = ((max_tgt_n + pad - 1) / pad) * pad;
+  if (need < pad) need = pad;
   const int tile_points = (int)(need < cap ? need : cap);
   a.tile_points = tile_points;
   a.tile_bytes = (uint32_t)(((size_t)tile_points * pt_bytes + 15) & ~(size_t)15);
+  a.w_bytes = (filter && dim == 2) ? (uint32_t)(((size_t)tile_points * sizeof(float) + 15) & ~(size_t)15) : 0u;
   const int kAcc = (dim == 2) ? AccLayout<2>::kTotal : AccLayout<3>::kTotal;
-  // keep the source cloud in LDS as well while two (big build) / four (small build) workgroups still fit a CU
-  const size_t budget = small ? 36 * 1024 : 72 * 1024;
+  // keep the source cloud in LDS as well: the small build while four workgroups still fit a CU; the big build
+  // (one workgroup per CU for its 128 VGPRs × up to 16 waves) while the whole workgroup stays below 128 KiB
+  const size_t budget = small ? 36 * 1024 : 128 * 1024;
   const size_t src_need = (((size_t)max_src_n * dim * sizeof(float)) + 15) & ~(size_t)15;
-  a.src_bytes = (a.tile_bytes + src_need <= budget && tune.src_in_lds != 2) || tune.src_in_lds == 1 ? (uint32_t)src_need : 0u;
-  const size_t smem = a.tile_bytes + a.src_bytes + sizeof(double) * ((size_t)kIcpBatchMaxWaves * kAcc + 16) + 16;
+  a.src_bytes = (a.tile_bytes + a.w_bytes + src_need <= budget && tune.src_in_lds != 2) || tune.src_in_lds == 1 ? (uint32_t)src_need : 0u;
+  const size_t smem = a.tile_bytes + a.w_bytes + a.src_bytes + sizeof(double) * ((size_t)kIcpBatchMaxWaves * kAcc + 16) + 16;
+  const Build build = small ? Build::kSmall : (filter ? Build::kFilter : Build::kBig);
 
   if (dim == 2) {
-    if (P == 1) return launch_one<2, 1>(a, S, threads, smem, small, stream);
-    if (P == 2) return launch_one<2, 2>(a, S, threads, smem, small, stream);
-    return launch_one<2, 4>(a, S, threads, smem, small, stream);
+    if (P == 1) return launch_one<2, 1>(a, S, threads, smem, build, stream);
+    if (P == 2) return launch_one<2, 2>(a, S, threads, smem, build, stream);
+    return launch_one<2, 4>(a, S, threads, smem, build, stream);
   }
-  if (P == 1) return launch_one<3, 1>(a, S, threads, smem, small, stream);
-  if (P == 2) return launch_one<3, 2>(a, S, threads, smem, small, stream);
-  return launch_one<3, 4>(a, S, threads, smem, small, stream);
+  if (P == 1) return launch_one<3, 1>(a, S, threads, smem, build, stream);
+  if (P == 2) return launch_one<3, 2>(a, S, threads, smem, build, stream);
+  return launch_one<3, 4>(a, S, threads, smem, build, stream);
 }
 
 }  // namespace lslam

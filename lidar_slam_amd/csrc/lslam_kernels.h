@@ -42,6 +42,7 @@ struct IcpBatchArgs {
   int32_t tile_points;       // filled by the launcher
   uint32_t tile_bytes;       // filled by the launcher
   uint32_t src_bytes;        // filled by the launcher: LDS reserved for the source cloud (0 = read it from memory)
+  uint32_t w_bytes;          // filled by the launcher: LDS reserved for |t|² per target (planar filter build, else 0)
 };
 
 struct IcpBatchTuning {
@@ -50,6 +51,7 @@ struct IcpBatchTuning {
   int tile_points = 0;       // 0 = default cap
   int variant = 0;           // 0 = automatic, 1 = force the 128-VGPR build, 2 = force the 64-VGPR build
   int src_in_lds = 0;        // 0 = automatic, 1 = always, 2 = never
+  int filter = 0;            // expanded-form filter sweep of the big build: 0 = automatic (on), 2 = off (exact sweep only)
 };
 
 // ---- exact chunk pruning (lslam_icp_pruned.hip) ----------------------------------------------------

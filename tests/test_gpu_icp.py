@@ -497,3 +497,83 @@ def test_sub_range_of_a_packed_buffer(icp, prune):
         np.testing.assert_array_equal(sub.iterations, full.iterations[lo:hi])
         np.testing.assert_array_equal(sub.correspondences[so[lo]:so[hi]], full.correspondences[so[lo]:so[hi]])
         np.testing.assert_allclose(sub.T, full.T[lo:hi], atol=1e-10)
+
+
+def _oracle_check(r, srcs, tgts, so, init, **kw):
+    from oracle import c_oracle
+    for k, (s, t) in enumerate(zip(srcs, tgts)):
+        To, eo, co, ito = c_oracle.run_icp(s, t, init[k], recipe="device", **kw)
+        assert r.iterations[k] == ito, k
+        np.testing.assert_array_equal(r.correspondences[so[k]:so[k + 1]], co, err_msg=f"problem {k}")
+        np.testing.assert_allclose(r.T[k], To, atol=1e-9, err_msg=f"problem {k}")
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("ppl", ["1", "2", "4"])
+def test_filter_sweep_gives_the_exact_answers(icp, dim, ppl, monkeypatch):
+    """the big build's expanded-form filter (|t|² − 2a·t, then the exact recipe on the chunks within the rounding
+    bound) against the C oracle's exact device recipe: random clouds at several scales, duplicates, clouds far from
+    the origin (bound too loose: the wave must fall back), tiny and ragged sizes — and against the same build with the filter off"""
+    from lidar_slam_amd.batch import icp_batch, pack_clouds
+    monkeypatch.setenv("LSLAM_ICP_VARIANT", "1")            # the big build whatever the size
+    monkeypatch.setenv("LSLAM_ICP_POINTS_PER_LANE", ppl)
+    rng = np.random.default_rng(7000 + dim)
+    sizes = [(3000, 4000), (8, 6), (70, 33), (4096, 4096), (1500, 31), (1000, 32), (2000, 2049), (640, 3000), (1300, 700)]
+    if dim == 3:
+        sizes = [(n, min(m, 4096)) for n, m in sizes]
+    ss, ts = [], []
+    for k, (n, m) in enumerate(sizes):
+        s_, t_ = _random_problem(rng, dim, n, m, spread=[0.05, 1.0, 10.0, 300.0][k % 4])
+        if m > 40:
+            t_[m // 2] = t_[3]; t_[m - 1] = t_[3]           # exact duplicates in different chunks
+        if k == 6:
+            s_ += 5000.0; t_ += 5000.0                       # far from the origin: |t|² − 2a·t loses every digit that matters
+        if k == 7:
+            s_[:, 0] += 80.0; t_[:, 0] += 80.0
+        ss.append(s_); ts.append(t_)
+    fs, so = pack_clouds(ss)
+    ft, to = pack_clouds(ts)
+    I = np.tile(np.eye(4), (len(sizes), 1, 1))
+    kw = dict(epsilon=1e-12, max_iters=6)
+    r = icp_batch(fs, so, ft, to, I, return_correspondences=True, **kw)
+    _oracle_check(r, ss, ts, so, I, **kw)
+    monkeypatch.setenv("LSLAM_ICP_FILTER", "0")
+    e = icp_batch(fs, so, ft, to, I, return_correspondences=True, **kw)
+    np.testing.assert_array_equal(r.correspondences, e.correspondences)
+    np.testing.assert_array_equal(r.iterations, e.iterations)
+    np.testing.assert_array_equal(r.T, e.T)                  # same pairs, same float64 summation order: identical bits
+
+
+def test_filter_sweep_on_lattices_and_collapsed_clouds(icp, monkeypatch):
+    """massive ties (every chunk minimum equal): the filter must hand over to the exact sweep, lowest index wins"""
+    from lidar_slam_amd.batch import icp_batch, pack_clouds
+    monkeypatch.setenv("LSLAM_ICP_VARIANT", "1")
+    rng = np.random.default_rng(11)
+    gx, gy = np.meshgrid(np.arange(60) * 0.25, np.arange(60) * 0.25)
+    lattice = np.column_stack((gx.ravel(), gy.ravel()))                      # 3600 points
+    shuffled = lattice[rng.permutation(lattice.shape[0])]
+    cases = [
+        (lattice + 0.125, shuffled),
+        (shuffled[:3000], np.vstack((lattice[:2000], lattice[:2000][::-1]))),
+        (rng.normal(size=(2700, 2)), np.tile([[1.5, -2.0]], (300, 1))),
+        (np.tile([[0.3, 0.3]], (2600, 1)), lattice),
+        (lattice, lattice),
+        (rng.normal(size=(3000, 2)) * 1e-3, rng.normal(size=(3000, 2)) * 1e-3),      # sub-millimetre cloud
+        (rng.normal(size=(2600, 2)) * 1e-18, rng.normal(size=(2600, 2)) * 1e-18),    # squares in the subnormal range
+    ]
+    fs, so = pack_clouds([c[0] for c in cases])
+    ft, to = pack_clouds([c[1] for c in cases])
+    I = np.tile(np.eye(4), (len(cases), 1, 1))
+    kw = dict(epsilon=1e-30, max_iters=2, return_correspondences=True)
+    a = icp_batch(fs, so, ft, to, I, **kw)
+    monkeypatch.setenv("LSLAM_ICP_FILTER", "0")
+    b = icp_batch(fs, so, ft, to, I, **kw)
+    np.testing.assert_array_equal(a.correspondences, b.correspondences)
+    np.testing.assert_array_equal(a.iterations, b.iterations)
+    np.testing.assert_array_equal(a.T, b.T)
+    # first iteration of case 0 against a direct evaluation: lowest index among the 4 equidistant corners
+    monkeypatch.delenv("LSLAM_ICP_FILTER")
+    s32, t32 = (lattice + 0.125).astype(np.float32), shuffled.astype(np.float32)
+    one = icp_batch(s32, [0, 3600], t32, [0, 3600], np.eye(4)[None], epsilon=0.0, max_iters=0, stopping_thresh=0.0, return_correspondences=True)
+    d = ((s32[:, None, :] - t32[None, :, :]) ** 2).sum(-1)
+    np.testing.assert_array_equal(one.correspondences, np.argmin(d, axis=1))
