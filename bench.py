@@ -172,7 +172,7 @@ def main():
         def step():
             B.icp_batch_dev(src.data_ptr(), off.data_ptr(), tgt.data_ptr(), off.data_ptr(), 2, init.data_ptr(), S, P, P,
                             out_T.data_ptr(), out_err.data_ptr(), out_it.data_ptr(), None, epsilon=0.0,
-                            max_iters=I - 1, stopping_thresh=0.0, stream=stream)
+                            max_iters=I - 1, stopping_thresh=0.0, stream=stream, prune=False)
             if use_dist:
                 dist.all_gather_into_tensor(gathered, out_T)       # the one collective: relative poses
 
@@ -185,7 +185,7 @@ def main():
             ev[k][0].record()
             B.icp_batch_dev(src.data_ptr(), off.data_ptr(), tgt.data_ptr(), off.data_ptr(), 2, init.data_ptr(), S, P, P,
                             out_T.data_ptr(), out_err.data_ptr(), out_it.data_ptr(), None, epsilon=0.0,
-                            max_iters=I - 1, stopping_thresh=0.0, stream=stream)
+                            max_iters=I - 1, stopping_thresh=0.0, stream=stream, prune=False)
             ev[k][1].record()
             if use_dist:
                 dist.all_gather_into_tensor(gathered, out_T)
@@ -412,12 +412,12 @@ def other_config(name, a, torch, device, stream, timed):
         def run():
             B.icp_batch_dev(s.data_ptr(), off.data_ptr(), t.data_ptr(), off.data_ptr(), 2, init.data_ptr(), 1, 1081, 1081,
                             oT.data_ptr(), oe.data_ptr(), oi.data_ptr(), None, epsilon=0.0, max_iters=a.iters - 1,
-                            stopping_thresh=0.0, stream=stream)
+                            stopping_thresh=0.0, stream=stream, prune=False)
         ms = _time(torch, run, 3, 20)
         res = {}
         def run_chip():
             res["r"] = B.icp_large_dev(s.data_ptr(), 1081, t.data_ptr(), 1081, 2, np.eye(4), epsilon=0.0, max_iters=a.iters - 1,
-                                       stopping_thresh=0.0, poll_every=a.iters, stream=stream)
+                                       stopping_thresh=0.0, poll_every=a.iters, stream=stream, prune=False)
         ms_chip = _time(torch, run_chip, 3, 20)
         out = {"workload": "C2 single planar pair 1081x1081, 50 forced iterations", "ms_one_workgroup": ms, "ms_whole_chip": ms_chip,
                "ms": min(ms, ms_chip), "iterations_per_sec": a.iters / (min(ms, ms_chip) * 1e-3),
@@ -436,7 +436,7 @@ def other_config(name, a, torch, device, stream, timed):
         res = {}
         def run():
             res["r"] = B.icp_large_dev(s.data_ptr(), s.shape[0], t.data_ptr(), t.shape[0], 3, T0, epsilon=0.0, max_iters=19,
-                                       stopping_thresh=0.0, poll_every=20, stream=stream)
+                                       stopping_thresh=0.0, poll_every=20, stream=stream, prune=False)
         ms = _time(torch, run, 2, 3)
         T, err, it = res["r"]
         def run_pruned():

@@ -76,12 +76,21 @@ int         lslam_valu_probe(int device, double *out_lane_ops_per_s);
  *   flags      LSLAM_ICP_* bits
  */
 #define LSLAM_ICP_NORMALIZE_ERROR 1u   /* icp.py:91-97 */
-/* Opt-in exact pruning: put both clouds into Morton order once per problem and skip, with a
- * float32-safe bound, every group of target points whose bounding box cannot hold a nearer (or equally
- * near) point for any source of a wave.  Same correspondences, iteration counts and (to float64
- * summation order) transforms as the plain all-pairs sweep.  Batched entry points: planar problems of
- * at most 4096 points per cloud (ignored otherwise); lslam_icp_large*: any size, planar or 3-D. */
-#define LSLAM_ICP_PRUNE 2u
+/* How the nearest neighbours are searched.  Both strategies return the same correspondences, iteration
+ * counts and (to float64 summation order) transforms:
+ *   all pairs   every source against every target out of LDS (the big batch build sweeps the expanded form
+ *               |t|^2 - 2 a.t first and re-evaluates, with the exact recipe, only the chunks its rounding bound
+ *               cannot exclude);
+ *   pruning     both clouds are put into Morton order once per problem and every group of target points whose
+ *               bounding box cannot hold a nearer (or equally near) point for any source of a wave is skipped,
+ *               with a float32-safe bound.  Batched entry points: planar problems of at most 4096 points per
+ *               cloud; lslam_icp_large*: any size, planar or 3-D.
+ * With neither bit set the library picks: pruning where it is supported and measured faster (batched planar
+ * problems from 512 points per cloud, one large pair from 2.5*10^8 (planar) / 10^9 (3-D) pair evaluations per
+ * iteration; measured with tools/prune_threshold.py), all pairs elsewhere.
+ * The environment variable LSLAM_ICP_PRUNE (0 / 1) changes that default; an explicit bit wins over it. */
+#define LSLAM_ICP_PRUNE 2u       /* force pruning (ignored where unsupported) */
+#define LSLAM_ICP_ALL_PAIRS 4u   /* force the all-pairs sweep */
 
 int lslam_icp_batch(const float *src, const int64_t *src_off,
                     const float *tgt, const int64_t *tgt_off,

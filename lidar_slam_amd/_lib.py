@@ -11,6 +11,12 @@ LIB_PATH = os.path.join(_HERE, "lib", "liblslam_hip.so")
 OK, ERR_BAD_ARG, ERR_EMPTY_TARGET, ERR_NONFINITE, ERR_HIP = 0, -1, -2, -3, -4
 ICP_NORMALIZE_ERROR = 1
 ICP_PRUNE = 2
+ICP_ALL_PAIRS = 4
+
+
+def search_flags(prune):
+    """prune=None: the library picks (LSLAM_ICP_* in include/lslam.h); True / False force pruning / the all-pairs sweep"""
+    return 0 if prune is None else (ICP_PRUNE if prune else ICP_ALL_PAIRS)
 PRE_POLAR, PRE_DBSCAN, PRE_RADIAL = 1, 2, 4
 
 

@@ -76,14 +76,14 @@ def pack_clouds(clouds):
 
 
 def icp_batch(src, src_off, tgt, tgt_off, init_T, epsilon=0.01, max_iters=2000, stopping_thresh=0.0001,
-              normalize_error=False, return_correspondences=False, device=0, prune=False) -> IcpBatchResult:
+              normalize_error=False, return_correspondences=False, device=0, prune=None) -> IcpBatchResult:
     """S independent run_icp problems (modules/icp.py:123-189) in one launch, host arrays in/out.
 
     src, tgt: float32 (N,d) packed clouds (d = 2 or 3; they may be the same array for a scan
     sequence); src_off, tgt_off: int64 (S+1,) point offsets; init_T: (S,4,4) float64.
-    ``prune=True`` (planar problems of ≤ 4096 points per cloud) sorts both clouds spatially and skips
-    target chunks that provably cannot hold a nearer point — same correspondences and iteration
-    counts, several times fewer pair evaluations."""
+    ``prune``: None = the library picks the search strategy, True = exact spatial pruning (planar problems of
+    ≤ 4096 points per cloud: both clouds sorted spatially, target chunks that provably cannot hold a nearer
+    point skipped), False = the all-pairs sweep.  Same correspondences and iteration counts either way."""
     src = np.ascontiguousarray(src, dtype=np.float32)
     tgt = src if tgt is src else np.ascontiguousarray(tgt, dtype=np.float32)
     if src.ndim != 2 or src.shape[1] not in (2, 3) or tgt.ndim != 2 or tgt.shape[1] != src.shape[1]:
@@ -100,7 +100,7 @@ def icp_batch(src, src_off, tgt, tgt_off, init_T, epsilon=0.01, max_iters=2000, 
     out_err = np.empty(S, dtype=np.float64)
     out_it = np.empty(S, dtype=np.int32)
     corr = np.empty(int(src_off[-1]) if S else 0, dtype=np.int32) if return_correspondences else None
-    flags = (_lib.ICP_NORMALIZE_ERROR if normalize_error else 0) | (_lib.ICP_PRUNE if prune else 0)
+    flags = (_lib.ICP_NORMALIZE_ERROR if normalize_error else 0) | _lib.search_flags(prune)
     check(lib().lslam_icp_batch(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), src.shape[1], ptr(init_T), S,
                                 float(epsilon), float(stopping_thresh), int(max_iters), flags,
                                 ptr(out_T), ptr(out_err), ptr(out_it), ptr(corr), int(device)))
@@ -109,9 +109,9 @@ def icp_batch(src, src_off, tgt, tgt_off, init_T, epsilon=0.01, max_iters=2000, 
 
 def icp_batch_dev(d_src, d_src_off, d_tgt, d_tgt_off, dim, d_init_T, S, max_src_n, max_tgt_n,
                   d_out_T, d_out_err, d_out_iters, d_out_corr=None, epsilon=0.01, max_iters=2000,
-                  stopping_thresh=0.0001, normalize_error=False, stream=0, prune=False) -> None:
+                  stopping_thresh=0.0001, normalize_error=False, stream=0, prune=None) -> None:
     """Same on DEVICE pointers (ints, e.g. torch.Tensor.data_ptr()); enqueues and returns."""
-    flags = (_lib.ICP_NORMALIZE_ERROR if normalize_error else 0) | (_lib.ICP_PRUNE if prune else 0)
+    flags = (_lib.ICP_NORMALIZE_ERROR if normalize_error else 0) | _lib.search_flags(prune)
     check(lib().lslam_icp_batch_dev(d_src, d_src_off, d_tgt, d_tgt_off, int(dim), d_init_T, int(S),
                                     int(max_src_n), int(max_tgt_n), float(epsilon), float(stopping_thresh),
                                     int(max_iters), flags, d_out_T, d_out_err, d_out_iters,
@@ -119,14 +119,15 @@ def icp_batch_dev(d_src, d_src_off, d_tgt, d_tgt_off, dim, d_init_T, S, max_src_
 
 
 def icp_large_dev(d_src, n, d_tgt, m, dim, init_T, epsilon=0.01, max_iters=2000, stopping_thresh=0.0001,
-                  normalize_error=False, d_out_corr=None, poll_every=8, stream=0, prune=False):
+                  normalize_error=False, d_out_corr=None, poll_every=8, stream=0, prune=None):
     """run_icp on one large cloud pair resident on the device; returns (T, error, iterations).
-    ``prune=True``: Morton-sorted clouds + a box hierarchy over the target, exact results."""
+    ``prune``: None = automatic, True = Morton-sorted clouds + a box hierarchy over the target, False = all pairs;
+    exact results either way."""
     init_T = np.ascontiguousarray(init_T, dtype=np.float64).reshape(4, 4)
     out_T = np.empty((4, 4), dtype=np.float64)
     out_err = np.empty(1, dtype=np.float64)
     out_it = np.empty(1, dtype=np.int32)
-    flags = (_lib.ICP_NORMALIZE_ERROR if normalize_error else 0) | (_lib.ICP_PRUNE if prune else 0)
+    flags = (_lib.ICP_NORMALIZE_ERROR if normalize_error else 0) | _lib.search_flags(prune)
     check(lib().lslam_icp_large_dev(d_src, int(n), d_tgt, int(m), int(dim), ptr(init_T), float(epsilon),
                                     float(stopping_thresh), int(max_iters), flags, int(poll_every),
                                     ptr(out_T), ptr(out_err), ptr(out_it), d_out_corr or None, stream or None))

@@ -89,6 +89,14 @@ static int check_offsets(const int64_t* off, int32_t S, const char* what, int64_
   return LSLAM_OK;
 }
 
+// search strategy of a call: explicit flag bits win, then LSLAM_ICP_PRUNE in the environment, then `automatic`
+static bool want_pruning(uint32_t flags, bool automatic) {
+  if (flags & kFlagAllPairs) return false;
+  if (flags & kFlagPrune) return true;
+  if (const char* e = getenv("LSLAM_ICP_PRUNE")) return atoi(e) != 0;
+  return automatic;
+}
+
 static IcpBatchTuning tuning_from_env() {
   IcpBatchTuning t;
   if (const char* e = getenv("LSLAM_ICP_POINTS_PER_LANE")) t.points_per_lane = atoi(e);
@@ -179,8 +187,7 @@ static int icp_batch_dev_impl(const float* d_src, const int64_t* d_src_off, cons
   a.init_T = d_init_T; a.out_T = d_out_T; a.out_err = d_out_err; a.out_iters = d_out_iters;
   a.out_corr = d_out_corr;
   a.epsilon = epsilon; a.stopping_thresh = stopping_thresh; a.max_iters = max_iters; a.flags = flags;
-  bool prune = (flags & kFlagPrune) != 0;
-  if (const char* e = getenv("LSLAM_ICP_PRUNE")) prune = atoi(e) != 0;
+  const bool prune = want_pruning(flags, max_src_n >= kAutoPruneBatchPoints && max_tgt_n >= kAutoPruneBatchPoints);
   if (prune && icp_pruned_supported(dim, max_src_n, max_tgt_n)) {
     // sorted copies in pair-local slots of S x max points (the offsets live on the device and may start anywhere)
     static thread_local PruneScratch sc{};
@@ -388,8 +395,7 @@ static int icp_large_dev_impl(const float* d_src, int64_t n, const float* d_tgt,
   int dev = 0;
   LSLAM_HIP_TRY(hipGetDevice(&dev));
   LargeWs& ws = large_ws();
-  bool prune = (flags & kFlagPrune) != 0;
-  if (const char* e = getenv("LSLAM_ICP_PRUNE")) prune = atoi(e) != 0;
+  const bool prune = want_pruning(flags, (double)n * (double)m >= (dim == 2 ? kAutoPruneLargePairEvals2D : kAutoPruneLargePairEvals3D));
   const NnGeometry geo = nn_geometry(dim, n, m);
   int rc = ws.ensure(dev, prune ? 1 : n * geo.splits);
   if (rc != LSLAM_OK) return rc;

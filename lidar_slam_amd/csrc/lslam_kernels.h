@@ -56,6 +56,10 @@ struct IcpBatchTuning {
 
 // ---- exact chunk pruning (lslam_icp_pruned.hip) ----------------------------------------------------
 constexpr uint32_t kFlagPrune = 2u;        // == LSLAM_ICP_PRUNE
+constexpr uint32_t kFlagAllPairs = 4u;     // == LSLAM_ICP_ALL_PAIRS
+constexpr int64_t kAutoPruneBatchPoints = 512;          // automatic choice: batched planar problems from this many points per cloud
+constexpr double kAutoPruneLargePairEvals3D = 1e9;      // one large pair: from this many pair evaluations per iteration (tools/prune_threshold.py)
+constexpr double kAutoPruneLargePairEvals2D = 2.5e8;
 constexpr int kPruneMaxPoints = 4096;      // per cloud: both sorted clouds + boxes + indices must fit LDS
 struct PruneScratch {                      // Morton-sorted copies: problem k owns slot [k·stride, (k+1)·stride)
   float2* src_sorted; uint16_t* src_index;

@@ -24,11 +24,11 @@ LARGE_PAIR_EVALS = 300_000
 
 _DEVICE = 0
 
-# Exact spatial pruning of the nearest-neighbour search (LSLAM_ICP_PRUNE in include/lslam.h): same
-# correspondences and iteration counts, several times fewer pair evaluations on clouds of thousands of
-# points.  Off by default (the all-pairs sweep is the path this package is specified by); the reference's
-# signatures stay untouched, so it is a module switch rather than an argument.
-PRUNE = False
+# Search strategy of the nearest-neighbour step (LSLAM_ICP_PRUNE / LSLAM_ICP_ALL_PAIRS in include/lslam.h): None
+# lets the library pick, True forces the exact spatial pruning, False the all-pairs sweep.  Same correspondences
+# and iteration counts either way; the reference's signatures stay untouched, so it is a module switch rather
+# than an argument.
+PRUNE = None
 
 
 def set_device(device: int) -> None:
@@ -154,7 +154,7 @@ def _solve_near(src, tgt, T0, epsilon, max_iters, stopping_thresh, normalize_err
         err = np.empty(1, dtype=np.float64)
         it = np.empty(1, dtype=np.int32)
         corr = np.empty(n, dtype=np.int32)
-        flags = (_lib.ICP_NORMALIZE_ERROR if normalize_error else 0) | (_lib.ICP_PRUNE if PRUNE else 0)
+        flags = (_lib.ICP_NORMALIZE_ERROR if normalize_error else 0) | _lib.search_flags(PRUNE)
         check(lib().lslam_icp_large(ptr(s32), n, ptr(t32), m, dim, ptr(T0), float(epsilon),
                                     float(stopping_thresh), int(max_iters), flags, ptr(T), ptr(err),
                                     ptr(it), ptr(corr), _DEVICE))

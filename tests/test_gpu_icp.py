@@ -8,6 +8,17 @@ from conftest import TOL_ROT, TOL_TRANS, golden, split
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["all_pairs", "auto"])
+def search_default(request, monkeypatch):
+    """every test of this file runs twice: with the all-pairs sweep as the library's default search strategy and
+    with the automatic choice (exact pruning where supported); an explicit prune= argument wins over either"""
+    if request.param == "all_pairs":
+        monkeypatch.setenv("LSLAM_ICP_PRUNE", "0")
+    else:
+        monkeypatch.delenv("LSLAM_ICP_PRUNE", raising=False)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def icp():
     import lidar_slam_amd
@@ -396,7 +407,7 @@ def test_exact_pruning_gives_the_brute_force_answers(icp):
     from lidar_slam_amd.synth import batch_c4
     g = golden("icp_planar.npz")
     srcs, flat, off, tgt, toff, init = batch_of(g)
-    a = icp_batch(flat, off, tgt, toff, init, epsilon=0.001, return_correspondences=True)
+    a = icp_batch(flat, off, tgt, toff, init, epsilon=0.001, return_correspondences=True, prune=False)
     b = icp_batch(flat, off, tgt, toff, init, epsilon=0.001, return_correspondences=True, prune=True)
     np.testing.assert_array_equal(b.iterations, a.iterations)
     np.testing.assert_array_equal(b.correspondences, a.correspondences)
@@ -415,21 +426,21 @@ def test_exact_pruning_gives_the_brute_force_answers(icp):
     ft, to = pack_clouds(ts)
     I = np.tile(np.eye(4), (len(sizes), 1, 1))
     for norm in (False, True):
-        a = icp_batch(fs, so, ft, to, I, epsilon=1e-12, max_iters=12, normalize_error=norm, return_correspondences=True)
+        a = icp_batch(fs, so, ft, to, I, epsilon=1e-12, max_iters=12, normalize_error=norm, return_correspondences=True, prune=False)
         b = icp_batch(fs, so, ft, to, I, epsilon=1e-12, max_iters=12, normalize_error=norm, return_correspondences=True, prune=True)
         np.testing.assert_array_equal(b.iterations, a.iterations)
         np.testing.assert_array_equal(b.correspondences, a.correspondences)
         np.testing.assert_allclose(b.T, a.T, atol=1e-10)
 
     w = batch_c4(24, 4096, seed=5)                           # the benchmark's shape
-    a = icp_batch(w.src, w.src_off, w.tgt, w.tgt_off, w.init_T, epsilon=0.0, stopping_thresh=0.0, max_iters=9, return_correspondences=True)
+    a = icp_batch(w.src, w.src_off, w.tgt, w.tgt_off, w.init_T, epsilon=0.0, stopping_thresh=0.0, max_iters=9, return_correspondences=True, prune=False)
     b = icp_batch(w.src, w.src_off, w.tgt, w.tgt_off, w.init_T, epsilon=0.0, stopping_thresh=0.0, max_iters=9, return_correspondences=True, prune=True)
     np.testing.assert_array_equal(b.correspondences, a.correspondences)
     np.testing.assert_allclose(b.T, a.T, atol=1e-11)
 
     # above the size limit the flag is ignored (plain sweep), not an error
     s_, t_ = _random_problem(rng, 2, 5000, 5000, 3.0)
-    a = icp_batch(*pack_clouds([s_]), *pack_clouds([t_]), np.eye(4)[None], max_iters=3, epsilon=1e-12, return_correspondences=True)
+    a = icp_batch(*pack_clouds([s_]), *pack_clouds([t_]), np.eye(4)[None], max_iters=3, epsilon=1e-12, return_correspondences=True, prune=False)
     b = icp_batch(*pack_clouds([s_]), *pack_clouds([t_]), np.eye(4)[None], max_iters=3, epsilon=1e-12, return_correspondences=True, prune=True)
     np.testing.assert_array_equal(b.correspondences, a.correspondences)
     np.testing.assert_array_equal(b.T, a.T)
@@ -453,7 +464,7 @@ def test_pruning_on_degenerate_clouds_with_massive_ties(icp):
     fs, so = pack_clouds([c[0] for c in cases])
     ft, to = pack_clouds([c[1] for c in cases])
     I = np.tile(np.eye(4), (len(cases), 1, 1))
-    a = icp_batch(fs, so, ft, to, I, epsilon=1e-30, max_iters=2, return_correspondences=True)
+    a = icp_batch(fs, so, ft, to, I, epsilon=1e-30, max_iters=2, return_correspondences=True, prune=False)
     b = icp_batch(fs, so, ft, to, I, epsilon=1e-30, max_iters=2, return_correspondences=True, prune=True)
     np.testing.assert_array_equal(b.correspondences, a.correspondences)
     np.testing.assert_array_equal(b.iterations, a.iterations)
@@ -469,6 +480,7 @@ def test_pruning_on_degenerate_clouds_with_massive_ties(icp):
 
 def test_module_switch_for_pruning_keeps_run_icp_results(icp, monkeypatch):
     g = golden("icp_3d.npz")
+    monkeypatch.setattr(icp, "PRUNE", False)
     ref = icp.run_icp(g["src"], g["tgt"], g["init"][1], 0.001, return_error=True, normalize_error=True, return_correspondences=True)
     monkeypatch.setattr(icp, "PRUNE", True)
     got = icp.run_icp(g["src"], g["tgt"], g["init"][1], 0.001, return_error=True, normalize_error=True, return_correspondences=True)
@@ -491,7 +503,7 @@ def test_sub_range_of_a_packed_buffer(icp, prune):
     ft, to = pack_clouds(list(ts))
     I = np.tile(np.eye(4), (len(sizes), 1, 1))
     kw = dict(epsilon=1e-12, max_iters=8, return_correspondences=True)
-    full = icp_batch(fs, so, ft, to, I, **kw)
+    full = icp_batch(fs, so, ft, to, I, prune=False, **kw)
     for lo, hi in ((6, 10), (3, 4), (9, 10)):
         sub = icp_batch(fs, so[lo:hi + 1], ft, to[lo:hi + 1], I[lo:hi], prune=prune, **kw)
         np.testing.assert_array_equal(sub.iterations, full.iterations[lo:hi])
@@ -535,10 +547,10 @@ def test_filter_sweep_gives_the_exact_answers(icp, dim, ppl, monkeypatch):
     ft, to = pack_clouds(ts)
     I = np.tile(np.eye(4), (len(sizes), 1, 1))
     kw = dict(epsilon=1e-12, max_iters=6)
-    r = icp_batch(fs, so, ft, to, I, return_correspondences=True, **kw)
+    r = icp_batch(fs, so, ft, to, I, return_correspondences=True, prune=False, **kw)
     _oracle_check(r, ss, ts, so, I, **kw)
     monkeypatch.setenv("LSLAM_ICP_FILTER", "0")
-    e = icp_batch(fs, so, ft, to, I, return_correspondences=True, **kw)
+    e = icp_batch(fs, so, ft, to, I, return_correspondences=True, prune=False, **kw)
     np.testing.assert_array_equal(r.correspondences, e.correspondences)
     np.testing.assert_array_equal(r.iterations, e.iterations)
     np.testing.assert_array_equal(r.T, e.T)                  # same pairs, same float64 summation order: identical bits
@@ -564,7 +576,7 @@ def test_filter_sweep_on_lattices_and_collapsed_clouds(icp, monkeypatch):
     fs, so = pack_clouds([c[0] for c in cases])
     ft, to = pack_clouds([c[1] for c in cases])
     I = np.tile(np.eye(4), (len(cases), 1, 1))
-    kw = dict(epsilon=1e-30, max_iters=2, return_correspondences=True)
+    kw = dict(epsilon=1e-30, max_iters=2, return_correspondences=True, prune=False)
     a = icp_batch(fs, so, ft, to, I, **kw)
     monkeypatch.setenv("LSLAM_ICP_FILTER", "0")
     b = icp_batch(fs, so, ft, to, I, **kw)
@@ -574,6 +586,6 @@ def test_filter_sweep_on_lattices_and_collapsed_clouds(icp, monkeypatch):
     # first iteration of case 0 against a direct evaluation: lowest index among the 4 equidistant corners
     monkeypatch.delenv("LSLAM_ICP_FILTER")
     s32, t32 = (lattice + 0.125).astype(np.float32), shuffled.astype(np.float32)
-    one = icp_batch(s32, [0, 3600], t32, [0, 3600], np.eye(4)[None], epsilon=0.0, max_iters=0, stopping_thresh=0.0, return_correspondences=True)
+    one = icp_batch(s32, [0, 3600], t32, [0, 3600], np.eye(4)[None], epsilon=0.0, max_iters=0, stopping_thresh=0.0, return_correspondences=True, prune=False)
     d = ((s32[:, None, :] - t32[None, :, :]) ** 2).sum(-1)
     np.testing.assert_array_equal(one.correspondences, np.argmin(d, axis=1))

@@ -61,12 +61,12 @@ while time.time() < t_end:
             bad += not same(f"batch prune={prune} dim={dim} n={probs[k][0].shape[0]} m={probs[k][1].shape[0]}", r.T[k], r.error[k],
                             r.iterations[k], r.correspondences[so[k]:so[k + 1]], o)
     for k, (s, t) in enumerate(probs[:6]):          # the same problems on the whole-chip path (fused below 8192 points)
-        for prune in (0, _lib.ICP_PRUNE):
+        for prune in (_lib.ICP_ALL_PAIRS, _lib.ICP_PRUNE):
             s32, t32 = np.ascontiguousarray(s, np.float32), np.ascontiguousarray(t, np.float32)
             T = np.empty((4, 4)); e = np.empty(1); it = np.empty(1, np.int32); corr = np.empty(s.shape[0], np.int32)
             check(lib().lslam_icp_large(ptr(s32), s.shape[0], ptr(t32), t.shape[0], dim, ptr(np.eye(4)), 1e-12, 1e-4, 12, prune,
                                         ptr(T), ptr(e), ptr(it), ptr(corr), 0))
-            bad += not same(f"whole-chip prune={prune != 0} dim={dim} n={s.shape[0]} m={t.shape[0]}", T, e[0], it[0], corr, oracles[k])
+            bad += not same(f"whole-chip prune={prune == _lib.ICP_PRUNE} dim={dim} n={s.shape[0]} m={t.shape[0]}", T, e[0], it[0], corr, oracles[k])
     rounds += 1; problems += len(probs)
     print(f"round {rounds}: {problems} problems so far, {bad} mismatches", flush=True)   # a silent long run is taken to be hung
 print(f"soak: {rounds} rounds, {problems} problems x (all-pairs, pruned) + {6 * rounds} x whole-chip (both): {bad} mismatches")
