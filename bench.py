@@ -26,22 +26,26 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-LANE_OPS_PER_PAIR_EVAL = 4.86        # SQ_INSTS_VALU x 64 / pair evaluations of icp_batch_kernel<2,4> (profiles/r01/pmc_traffic.json)
 PEAK_FP32_VECTOR_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CUs × 4 SIMD × 32 lanes × 2 flop × 2.4 GHz
 PEAK_HBM_TBS = 8.0
+HEADLINE_KERNEL = "icp_batch_filter_kernel<2,4>"
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
-    (profiles/rNN/pmc_traffic.json; collected with the same bench command, see that file)."""
+def profile_figures(workload, kernel):
+    """Figures that only a PMC pass can give (HBM bytes per launch, VALU instructions per pair evaluation), read from the
+    newest committed profiles/rNN/pmc_traffic.json and used ONLY if that file was taken on the kernel this run
+    launches — a stale entry (another kernel name) is not reported."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
-    if not files:
-        return None
-    try:
-        return json.load(open(files[-1]))[workload]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+        try:
+            e = json.load(open(f))[workload]
+        except Exception:
+            continue
+        if e.get("kernel") == kernel:
+            return {"hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "lane_ops_per_pair_eval": e.get("lane_ops_per_pair_eval"),
+                    "source": os.path.relpath(f, ROOT)}
+        return {}
+    return {}
 
 
 def parse():
@@ -141,6 +145,22 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if torch.cuda.device_count() < 1:                           # counting devices does not initialise HIP
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    # The CPU-baseline legs run BEFORE anything initialises HIP in this process: the all-cores leg forks a
+    # process pool, and a forked child of a GPU-initialised process inherits runtime threads and KFD mappings.
+    cpu_baseline = None
+    if rank == 0 and world == 1 and a.workload == "c4" and not a.no_cpu_baseline:
+        from lidar_slam_amd import synth
+        n = min(a.cpu_sample_pairs, a.pairs)
+        w = synth.batch_c4(n, a.points, seed=1000)              # same distribution as the device-side generator below
+        h_src, h_tgt = w.src.astype(np.float64), w.tgt.astype(np.float64)
+        v, secs, its = cpu_baseline_icp(h_src, h_tgt, w.init_T, a.points, n, a.iters)
+        vall, cores = cpu_baseline_all_cores(h_src, h_tgt, w.init_T, a.points, n, a.iters)
+        cpu_baseline = {"value": v, "unit": "iterations/s", "cores": 1, "kind": "port",
+                        "sample": f"{n} pairs of the C4 distribution ({a.points}x{a.points} planar), {a.iters} forced iterations each, "
+                                  f"oracle KDTree port of modules/icp.py, {secs:.1f} s",
+                        "all_cores_value": vall, "all_cores": cores, "cpu_model": _cpu_model()}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -206,43 +226,44 @@ def main():
         probe = ctypes.c_double(0.0)
         check(lib().lslam_valu_probe(local_rank, ctypes.byref(probe)))
         issue_rate = probe.value                                   # lane-ops/s this device sustains under an all-VALU load
+        prof = profile_figures("c4", HEADLINE_KERNEL)
         result = {
             "metric": "icp_iterations_per_sec", "value": total_iters / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C4 synthetic batch: {S} scan pairs per GPU x {P}x{P} planar points, {I} forced ICP iterations per pair",
-                       "pairs_per_gpu": S, "points": P, "iterations": I, "sharding": f"independent pairs over {world} GPU(s), all-gather of poses"},
+                       "pairs_per_gpu": S, "points": P, "iterations": I, "sharding": f"independent pairs over {world} GPU(s), all-gather of poses", "search": "all pairs (LSLAM_ICP_ALL_PAIRS)"},
             "scan_pairs_per_sec": world * S * a.steps / dt,
             "pair_evals_per_sec": world * pair_evals_per_launch * a.steps / dt,
-            "roofline": {"kernel": "icp_batch_kernel<2,4>", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS,
+            "roofline": {"kernel": HEADLINE_KERNEL if (P > 2560 and P <= 8192) else "icp_batch_*", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
-                         "traffic": measured_traffic("c4") if (S, P, I) == (4096, 4096, 50) else None,
+                         "traffic": prof.get("hbm_bytes_per_launch") if (S, P, I) == (4096, 4096, 50) else None,
                          "kernel_ms": kernel_ms, "algorithmic_flop_per_pair_eval": 5,
                          "pair_evals_per_s": pair_evals_per_launch / (kernel_ms * 1e-3),
-                         "device_valu_issue_lane_ops_per_s": issue_rate, "kernel_lane_ops_per_pair_eval": LANE_OPS_PER_PAIR_EVAL,
-                         "frac_of_device_valu_issue_ceiling": pair_evals_per_launch / (kernel_ms * 1e-3) * LANE_OPS_PER_PAIR_EVAL / issue_rate,
-                         "hbm_effective_untiled_TBps": pair_evals_per_launch * 8 / (kernel_ms * 1e-3) / 1e12,
-                         "hbm_effective_frac_of_8TBps": pair_evals_per_launch * 8 / (kernel_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
-                         "hbm_compulsory_bytes_per_launch": 2 * S * P * 8 + S * 2 * 128,
-                         "note": "fp32 VALU-issue bound (all-pairs NN out of LDS); HBM sees only the compulsory bytes. peak = fp32 vector peak"},
-            # the same launch priced against the HBM roof, for a reader who expects that bound: it is four orders away
-            "roofline_hbm": {"kernel": "icp_batch_kernel<2,4>", "bound": "hbm", "achieved": (2 * S * P * 8 + S * 2 * 128) / (kernel_ms * 1e-3) / 1e9,
+                         "device_valu_probe_lane_ops_per_s": issue_rate,
+                         "kernel_valu_instructions_per_pair_eval": prof.get("lane_ops_per_pair_eval"), "profile": prof.get("source"),
+                         "note": "float32 VALU-issue bound: the all-pairs sweep runs out of LDS (expanded form |t|^2 - 2a.t = 2 v_fma + 1 min per pair, "
+                                 "then the exact recipe on the chunks the rounding bound cannot exclude); HBM sees only the compulsory bytes. "
+                                 "peak = fp32 vector FMA peak; v_min3_f32 issues at half rate on gfx950 (profiles/r02/valu_probe2.txt), so 3 issue slots per pair is the floor of this form"},
+            # the same launch priced against the HBM roof, as the bench contract words it (algorithmic bytes / duration): four orders away, not the binding roof
+            "roofline_hbm": {"kernel": HEADLINE_KERNEL, "bound": "hbm", "achieved": (2 * S * P * 8 + S * 2 * 128) / (kernel_ms * 1e-3) / 1e9,
                              "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": (2 * S * P * 8 + S * 2 * 128) / (kernel_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
-                             "traffic": measured_traffic("c4") if (S, P, I) == (4096, 4096, 50) else None,
-                             "note": "algorithmic bytes = both clouds once + transforms in/out per problem, independent of the iteration count; not the binding roof"},
+                             "traffic": prof.get("hbm_bytes_per_launch") if (S, P, I) == (4096, 4096, 50) else None,
+                             "note": "algorithmic bytes = both clouds once + transforms in/out per problem, independent of the iteration count"},
         }
         if rank == 0 and world == 1:
-            # the same batch with exact chunk pruning (opt-in LSLAM_ICP_PRUNE flag; identical correspondences)
+            # the same batch as the library runs it when the caller does not force a strategy: exact pruning (identical correspondences)
             oT2 = torch.empty_like(out_T)
-            def step_pruned():
+            def step_auto():
                 B.icp_batch_dev(src.data_ptr(), off.data_ptr(), tgt.data_ptr(), off.data_ptr(), 2, init.data_ptr(), S, P, P,
                                 oT2.data_ptr(), out_err.data_ptr(), out_it.data_ptr(), None, epsilon=0.0,
-                                max_iters=I - 1, stopping_thresh=0.0, stream=stream, prune=True)
-            ms_p = _time(torch, step_pruned, 2, a.steps)
-            result["pruned"] = {"what": "same workload with LSLAM_ICP_PRUNE: Morton-sorted clouds, wave-uniform box tests, exact results",
-                                "ms_per_step": ms_p, "icp_iterations_per_sec": S * I / (ms_p * 1e-3),
-                                "speedup_vs_all_pairs_sweep": (dt / a.steps * 1e3) / ms_p,
-                                "max_abs_T_difference": float((oT2 - out_T).abs().max().item())}
+                                max_iters=I - 1, stopping_thresh=0.0, stream=stream)
+            ms_p = _time(torch, step_auto, 2, a.steps)
+            result["default_search_strategy"] = {"what": "same workload, search strategy left to the library (flags = 0): Morton-sorted clouds + exact box pruning "
+                                                         "(icp_sort_kernel + icp_pruned_kernel), identical correspondences and iteration counts",
+                                                 "ms_per_step": ms_p, "icp_iterations_per_sec": S * I / (ms_p * 1e-3),
+                                                 "speedup_vs_all_pairs_sweep": (dt / a.steps * 1e3) / ms_p,
+                                                 "max_abs_T_difference": float((oT2 - out_T).abs().max().item())}
         if rank == 0 and world == 1 and a.natural:
             # the same batch left to the reference's own stop rules (scan-matching call: epsilon 1e-3, defaults else).
             # Opt-in: it launches the headline kernel with a tenth of the work, which would blur that kernel's
@@ -257,14 +278,8 @@ def main():
             result["natural_convergence"] = {"what": "same batch, stop rules of the scan-matching call (epsilon 1e-3, stopping_thresh 1e-4, max_iters 2000)",
                                              "ms_per_step": ms_n, "iterations_total": its, "iterations_min_max": [int(out_it.min().item()), int(out_it.max().item())],
                                              "icp_iterations_per_sec": its / (ms_n * 1e-3), "scan_pairs_per_sec": S / (ms_n * 1e-3)}
-        if rank == 0 and world == 1 and not a.no_cpu_baseline:
-            n = min(a.cpu_sample_pairs, S)
-            h_src, h_tgt, h_init = src[: n * P].cpu().numpy().astype(np.float64), tgt[: n * P].cpu().numpy().astype(np.float64), init[:n].cpu().numpy()
-            v, secs, its = cpu_baseline_icp(h_src, h_tgt, h_init, P, n, I)
-            vall, cores = cpu_baseline_all_cores(h_src, h_tgt, h_init, P, n, I)
-            result["cpu_baseline"] = {"value": v, "unit": "iterations/s", "cores": 1, "kind": "port",
-                                      "sample": f"first {n} of the {S} pairs, {I} forced iterations each, oracle KDTree port of modules/icp.py, {secs:.1f} s",
-                                      "all_cores_value": vall, "all_cores": cores, "cpu_model": _cpu_model()}
+        if cpu_baseline is not None:
+            result["cpu_baseline"] = cpu_baseline
     else:
         result = other_config(a.workload, a, torch, device, stream, timed=True)
 
@@ -427,7 +442,6 @@ def other_config(name, a, torch, device, stream, timed):
                             "bound": "launch latency", "us_per_iteration": ms_chip * 1e3 / a.iters,
                             "achieved": a.iters * 1081.0 * 1081 * 5 / (ms_chip * 1e-3) / 1e12, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                             "frac": a.iters * 1081.0 * 1081 * 5 / (ms_chip * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
-                            "hbm_effective_frac_of_8TBps": a.iters * 1081.0 * 1081 * 8 / (ms_chip * 1e-3) / 1e12 / PEAK_HBM_TBS,
                             "note": "1.17 M pair evaluations per iteration are 0.1 us of chip time; an iteration is one dependent kernel launch "
                                     "(about 6 us of dispatch + the serial solve of the last workgroup)"}}
     elif name == "c5":
@@ -441,18 +455,16 @@ def other_config(name, a, torch, device, stream, timed):
         T, err, it = res["r"]
         def run_pruned():
             res["p"] = B.icp_large_dev(s.data_ptr(), s.shape[0], t.data_ptr(), t.shape[0], 3, T0, epsilon=0.0, max_iters=19,
-                                       stopping_thresh=0.0, poll_every=20, stream=stream, prune=True)
+                                       stopping_thresh=0.0, poll_every=20, stream=stream)
         ms_p = _time(torch, run_pruned, 2, 3)
         out = {"workload": "C5 dense 3-D 100k x 100k, 20 forced iterations, whole chip", "ms": ms, "iterations": it,
                "iterations_per_sec": it / (ms * 1e-3), "pair_evals_per_sec": it * 1e10 / (ms * 1e-3),
                "roofline": {"kernel": "nn_tiled_kernel<3,4> (+ moments_kernel<3>, solve_kernel<3> per iteration)", "bound": "valu",
                             "achieved": it * 1e10 * 8 / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                             "frac": it * 1e10 * 8 / (ms * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
-                            "hbm_effective_untiled_TBps": it * 1e10 * 12 / (ms * 1e-3) / 1e12,
-                            "hbm_effective_frac_of_8TBps": it * 1e10 * 12 / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
                             "hbm_compulsory_bytes_per_iteration": 12 * 2 * 100000 + 4 * 100000,
-                            "note": "8 algorithmic flop and 12 untiled bytes per 3-D pair evaluation; whole iteration (3 launches) timed, not the search kernel alone"},
-               "pruned": {"what": "same 20 iterations with LSLAM_ICP_PRUNE (Morton sort + box hierarchy, exact results; the sort is inside the timed call)",
+                            "note": "8 algorithmic flop per 3-D pair evaluation; whole iteration (3 launches) timed, not the search kernel alone"},
+               "default_search_strategy": {"what": "same 20 iterations, strategy left to the library (pruning above 1e9 pair evaluations per iteration: Morton sort + box hierarchy, exact results; the sort is inside the timed call)",
                           "ms": ms_p, "speedup": ms / ms_p, "max_abs_T_difference": float(np.abs(res["p"][0] - T).max())},
                "pose_err_vs_truth": float(np.abs(T - T_true).max())}
     elif name == "c3":

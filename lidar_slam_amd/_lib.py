@@ -6,7 +6,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblslam_hip.so")
+LIB_PATH = os.environ.get("LSLAM_LIB") or os.path.join(_HERE, "lib", "liblslam_hip.so")      # LSLAM_LIB: A/B runs of two builds
 
 OK, ERR_BAD_ARG, ERR_EMPTY_TARGET, ERR_NONFINITE, ERR_HIP = 0, -1, -2, -3, -4
 ICP_NORMALIZE_ERROR = 1

@@ -16,6 +16,8 @@
 // strict, so a skipped chunk can never hold the argmin or a tie.  Equal distances in two evaluated
 // chunks (duplicate points) are resolved by a rare exhaustive pass ordered by original index.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "lslam_device.h"
 #include "lslam_kernels.h"
@@ -32,6 +34,11 @@ __device__ __forceinline__ unsigned morton5(unsigned x, unsigned y) {      // in
 #pragma unroll
   for (int b = 0; b < 5; ++b) r |= ((x >> b) & 1u) << (2 * b) | ((y >> b) & 1u) << (2 * b + 1);
   return r;
+}
+
+// the next float above a non-negative finite float (or +inf)
+__device__ __forceinline__ float next_up(float v) {
+  return v < INFINITY ? __uint_as_float(__float_as_uint(v) + 1u) : v;
 }
 
 __device__ __forceinline__ float wave_min_f(float v) {
@@ -146,8 +153,8 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   float2* tile = reinterpret_cast<float2*>(smem);                                   // sorted targets, padded
   float4* aabb = reinterpret_cast<float4*>(smem + lay.aabb_off);                    // per chunk {x0,y0,x1,y1}
   float4* aabb2 = reinterpret_cast<float4*>(smem + lay.aabb2_off);                  // per super-chunk
-  uint16_t* tidx = reinterpret_cast<uint16_t*>(smem + lay.tidx_off);                // original target index
-  uint16_t* sh_prev = reinterpret_cast<uint16_t*>(smem + lay.prev_off);             // last match of every source
+  float2* sh_src = reinterpret_cast<float2*>(smem + lay.src_off);                   // sorted sources: read twice per iteration, so they live on chip
+  uint16_t* sh_prev = reinterpret_cast<uint16_t*>(smem + lay.prev_off);             // last match (sorted target position) of every source
   double* sh_red = reinterpret_cast<double*>(smem + lay.red_off);                   // [waves][kAcc]
   double* sh_T = sh_red + (size_t)kIcpBatchMaxWaves * kAcc;
   int* sh_flag = reinterpret_cast<int*>(sh_T + 16);
@@ -157,17 +164,18 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   const int64_t s0 = args.src_off[pair], t0 = args.tgt_off[pair];
   const int n = (int)(args.src_off[pair + 1] - s0), m = (int)(args.tgt_off[pair + 1] - t0);
   const int64_t ss = (int64_t)pair * sc.src_stride, ts = (int64_t)pair * sc.tgt_stride;   // pair-local scratch slots
-  const float2* __restrict__ ssrc = sc.src_sorted + ss;        // Morton-sorted sources (L2-resident)
+  const float2* __restrict__ ssrc = sc.src_sorted + ss;        // Morton-sorted sources
+  // original target index of a sorted position: only needed when two targets are equally near (rare) and for the
+  // correspondences written at the end, so it stays in global memory (the LDS it took lets the sources live on chip)
+  const uint16_t* __restrict__ tidx = sc.tgt_index + ts;
   const bool box = (args.flags & kFlagNormalize) != 0;
   const int nchunks = (m + CHUNK - 1) / CHUNK;
   const int nsuper = (nchunks + SUPER - 1) / SUPER;
 
   if (tid < 16) sh_T[tid] = args.init_T[(int64_t)16 * pair + tid];
-  for (int j = tid; j < nchunks * CHUNK; j += blockDim.x) {
-    tile[j] = (j < m) ? sc.tgt_sorted[ts + j] : make_float2(kFar, kFar);
-    tidx[j] = (j < m) ? sc.tgt_index[ts + j] : (uint16_t)0xffff;
-  }
-  for (int i = tid; i < n; i += blockDim.x) sh_prev[i] = 0xffff;
+  for (int j = tid; j < nchunks * CHUNK; j += blockDim.x) tile[j] = (j < m) ? sc.tgt_sorted[ts + j] : make_float2(kFar, kFar);
+  const bool src_lds = lay.src_off != 0xffffffffu;
+  for (int i = tid; i < n; i += blockDim.x) { if (src_lds) sh_src[i] = ssrc[i]; sh_prev[i] = 0xffff; }
   __syncthreads();
   for (int c = tid; c < nchunks; c += blockDim.x) {        // boxes over the real points only
     float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
@@ -212,7 +220,7 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
         const int i = base + tid * P + p;
         ax[p] = 0.f; ay[p] = 0.f;
         if (i < n) {
-          const float2 v = ssrc[i];
+          const float2 v = src_lds ? sh_src[i] : ssrc[i];
           ax[p] = (float)(T[0][0] * (double)v.x + T[0][1] * (double)v.y + T[0][3]);      // icp.py:116
           ay[p] = (float)(T[1][0] * (double)v.x + T[1][1] * (double)v.y + T[1][3]);
           wx0 = fminf(wx0, ax[p]); wy0 = fminf(wy0, ay[p]); wx1 = fmaxf(wx1, ax[p]); wy1 = fmaxf(wy1, ay[p]);
@@ -221,26 +229,27 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
       wx0 = wave_min_f(wx0); wy0 = wave_min_f(wy0); wx1 = wave_max_f(wx1); wy1 = wave_max_f(wy1);
 
       // ---- start from last iteration's match: a tight bound before the first chunk ------------
-      float best[P];
+      float best[P], second[P];                            // smallest and second smallest chunk minimum seen so far
       int bchunk[P];
       bool tie = false;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int i = base + tid * P + p;
         best[p] = (i < n) ? INFINITY : -INFINITY;          // lanes without a point never ask for a chunk
+        second[p] = INFINITY;
         bchunk[p] = 0;
         if (i < n) {
           const int pv = sh_prev[i];
           if (pv != 0xffff) {
             const float2 q = tile[pv];
-            best[p] = dist2(ax[p], ay[p], q.x, q.y);
+            best[p] = next_up(dist2(ax[p], ay[p], q.x, q.y));      // a bound, not yet a candidate: its chunk will beat it strictly
             bchunk[p] = pv / CHUNK;
           } else {
             // first iteration: both clouds are sorted along the same curve, so the target at the same
             // relative rank is usually close — any evaluated point is a valid upper bound
             const int g = (int)(((long long)i * m) / n);
             const float2 q = tile[g];
-            best[p] = dist2(ax[p], ay[p], q.x, q.y);
+            best[p] = next_up(dist2(ax[p], ay[p], q.x, q.y));
             bchunk[p] = g / CHUNK;
           }
         }
@@ -292,32 +301,48 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
               const float d1 = dist2(ax[p], ay[p], v[k].z, v[k].w);
               mn = fminf(fminf(d0, d1), mn);
             }
-            tie |= (mn == best[p]) && (c != bchunk[p]) && (mn < INFINITY);
+            // equal minima of two chunks are found through the VALUES (second smallest == smallest) after the sweep:
+            // no per-chunk compare into a scalar mask
             const bool lt = mn < best[p];
+            second[p] = __builtin_amdgcn_fmed3f(best[p], second[p], mn);
             bchunk[p] = lt ? c : bchunk[p];
             best[p] = lt ? mn : best[p];
           }
         }
       }
 
-      // ---- fix-up inside the winning chunk: (distance, original index) lexicographic ------------
-      int pos[P], oidx[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) tie |= (second[p] == best[p]) && (best[p] < INFINITY);
+      // ---- fix-up inside the winning chunk: position of the minimum; equal distances are left to the pass below ----
+      int pos[P];
       float bd[P];
+      int rot = lane;
+      asm volatile("" : "+v"(rot));                          // opaque: keeps the 16 rotated offsets from being hoisted out of the ICP loop (and spilled)
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int j0 = bchunk[p] * CHUNK;
-        bd[p] = INFINITY; pos[p] = j0; oidx[p] = 0x7fffffff;
+        float second = INFINITY;                             // second smallest distance of the chunk: equal to the smallest ⇔ two equally near targets
+        bd[p] = INFINITY; pos[p] = j0;
 #pragma unroll
         for (int kk = 0; kk < CHUNK; ++kk) {
-          const int k = (kk + lane) & (CHUNK - 1);
+          const int k = (kk + rot) & (CHUNK - 1);
           const float2 q = tile[j0 + k];
-          const int o = tidx[j0 + k];
           const float d = dist2(ax[p], ay[p], q.x, q.y);
-          if (d < bd[p] || (d == bd[p] && o < oidx[p])) { bd[p] = d; pos[p] = j0 + k; oidx[p] = o; }
+          // all in vector registers: a per-element compare into a scalar mask (v_cmp → s_and → s_or chains) was measured
+          // 1.5× slower for the whole kernel
+          const bool lt = d < bd[p];
+          second = __builtin_amdgcn_fmed3f(bd[p], second, d);
+          pos[p] = lt ? j0 + k : pos[p];
+          bd[p] = lt ? d : bd[p];
         }
+        tie |= (second == bd[p]) && (bd[p] < INFINITY);
       }
-      // ---- equal minima in different chunks (duplicate points): exhaustive pass by original index --
+      // ---- equal minima (duplicate or equidistant points, in one chunk or in two): exhaustive pass, lowest ORIGINAL index wins --
       if (__any(tie)) {
+        if (lay.debug_counter && lane == 0) atomicAdd(lay.debug_counter, 1u);
+        int oidx[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) { bd[p] = INFINITY; oidx[p] = 0x7fffffff; }
         for (int j = 0; j < m; ++j) {
           const float2 q = tile[j];
           const int o = tidx[j];
@@ -347,14 +372,13 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
         const int i = base + tid * P + p;
         if (i < n) {
           const int ps = sh_prev[i];
-          const float2 v = ssrc[i];
+          const float2 v = src_lds ? sh_src[i] : ssrc[i];
           const float2 q = tile[ps];
           double pd[2], qd[2];
           pd[0] = T[0][0] * (double)v.x + T[0][1] * (double)v.y + T[0][3];
           pd[1] = T[1][0] * (double)v.x + T[1][1] * (double)v.y + T[1][3];
           qd[0] = (double)q.x; qd[1] = (double)q.y;
           acc.add(pd, qd, box);
-          if (args.out_corr) args.out_corr[s0 + sc.src_index[ss + i]] = tidx[ps];
         }
       }
     }
@@ -403,6 +427,9 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
     args.out_err[pair] = err_out;
     args.out_iters[pair] = st.executed;
   }
+  // correspondences of the LAST iteration (icp.py:117, 187-189), in the caller's numbering
+  if (args.out_corr)
+    for (int i = tid; i < n; i += blockDim.x) args.out_corr[s0 + sc.src_index[ss + i]] = tidx[sh_prev[i]];
 }
 
 // ---- launch ------------------------------------------------------------------------------------------
@@ -432,7 +459,8 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   size_t off = (size_t)padded * sizeof(float2);
   lay.aabb_off = (uint32_t)off; off += (size_t)nchunks * sizeof(float4);
   lay.aabb2_off = (uint32_t)off; off += (size_t)nsuper * sizeof(float4);
-  lay.tidx_off = (uint32_t)off; off += up((size_t)padded * sizeof(uint16_t));
+  if (getenv("LSLAM_PRUNE_SRC_GLOBAL")) lay.src_off = 0xffffffffu;
+  else { lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(float2)); }
   lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));
   lay.red_off = (uint32_t)off;
   const size_t smem = off + sizeof(double) * ((size_t)kIcpBatchMaxWaves * AccLayout<2>::kTotal + 16) + 16;
@@ -440,6 +468,16 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
     if (smem > 48 * 1024) {
       hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (ee != hipSuccess) return ee;
+    }
+    static unsigned* dbg = nullptr;
+    if (getenv("LSLAM_DEBUG")) {
+      if (!dbg) { (void)hipMalloc(&dbg, 4); }
+      else { unsigned h = 0; (void)hipMemcpy(&h, dbg, 4, hipMemcpyDeviceToHost); fprintf(stderr, "[lslam] exhaustive tie passes of the previous launch: %u\n", h); }
+      (void)hipMemset(dbg, 0, 4);
+      lay.debug_counter = dbg;
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, smem);
+      fprintf(stderr, "[lslam] icp_pruned_kernel: %d threads, %zu B LDS, %d workgroups per CU\n", threads, smem, nb);
     }
     hipLaunchKernelGGL(kernel, dim3(S), dim3(threads), smem, stream, a, sc, lay);
     return hipGetLastError();
