@@ -274,7 +274,17 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
   const bool src_resident = (size_t)n * DIM * sizeof(float) <= args.src_bytes;
   if (src_resident)
     for (int i = tid; i < n * DIM; i += blockDim.x) sh_src[i] = gsrc[i];
-  const float* __restrict__ psrc = src_resident ? sh_src : gsrc;
+  // source point i as doubles, from LDS or from memory: two explicit paths (one generic pointer for both would make
+  // every read a flat load through a 64-bit per-point address)
+  auto load_src = [&](int i, double& x, double& y, double& z) {
+    if constexpr (DIM == 2) {
+      const float2 v = src_resident ? reinterpret_cast<const float2*>(sh_src)[i] : reinterpret_cast<const float2*>(gsrc)[i];
+      x = v.x; y = v.y;
+    } else {
+      if (src_resident) { x = sh_src[3 * i]; y = sh_src[3 * i + 1]; z = sh_src[3 * i + 2]; }
+      else { x = gsrc[3 * (int64_t)i]; y = gsrc[3 * (int64_t)i + 1]; z = gsrc[3 * (int64_t)i + 2]; }
+    }
+  };
   __syncthreads();
   float Rt = 0.f;                                              // ≥ the largest |t| of the problem
   if constexpr (FILTER) {
@@ -315,14 +325,7 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
     for (int p = 0; p < P; ++p) {
       const int i = base + tid * P + p;                  // lane-consecutive: tail waves own no point at all
       double x = 0.0, y = 0.0, z = 0.0;
-      if (i < n) {
-        if constexpr (DIM == 2) {
-          const float2 v = *reinterpret_cast<const float2*>(psrc + 2 * (int64_t)i);
-          x = v.x; y = v.y;
-        } else {
-          x = psrc[3 * (int64_t)i]; y = psrc[3 * (int64_t)i + 1]; z = psrc[3 * (int64_t)i + 2];
-        }
-      }
+      if (i < n) load_src(i, x, y, z);
 #pragma unroll
       for (int r = 0; r < DIM; ++r) {                        // icp.py:116
         double v = T[r][0] * x + T[r][1] * y + T[r][3];
@@ -349,6 +352,11 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
           for (int r = 0; r < DIM; ++r) na[p][r] = -2.f * a[p][r];
         }
         filter_sweep<DIM, P>(tile, wtile, m_padded / kFilterChunk, na, b1, b2, b3, i1, i2);
+        // a = −na/2 exactly: re-deriving it here keeps `a` out of the registers that are live across the sweep
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) a[p][r] = -0.5f * na[p][r];
         // rounding-error bound of g against the exact distance (see the header comment and DESIGN.md §3.1c)
         constexpr float kU = 5.97e-8f;                       // > 2⁻²⁴
         constexpr float kE = (DIM == 2 ? 4.5f : 6.5f) * kU;
@@ -455,12 +463,7 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
       const int i = base + tid * P + p;
       if (i < n) {
         double x, y, z = 0.0;
-        if constexpr (DIM == 2) {
-          const float2 v = *reinterpret_cast<const float2*>(psrc + 2 * (int64_t)i);
-          x = v.x; y = v.y;
-        } else {
-          x = psrc[3 * (int64_t)i]; y = psrc[3 * (int64_t)i + 1]; z = psrc[3 * (int64_t)i + 2];
-        }
+        load_src(i, x, y, z);
         double pd[DIM], qd[DIM];
 #pragma unroll
         for (int r = 0; r < DIM; ++r) {
