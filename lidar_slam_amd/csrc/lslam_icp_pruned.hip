@@ -25,7 +25,6 @@
 namespace lslam {
 
 constexpr int kPruneChunk = 16;
-constexpr int kPruneSuper = 8;
 constexpr int kSortThreads = 256;
 constexpr float kPruneSafety = 0.99999f;
 
@@ -147,12 +146,10 @@ template <int P>
 __global__ void __launch_bounds__(kIcpBatchMaxThreads, 8)      // ≤ 64 VGPRs: two 16-wave workgroups per CU (measured 1.3× faster than 119 VGPRs / one workgroup)
 icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   constexpr int CHUNK = kPruneChunk;
-  constexpr int SUPER = kPruneSuper;                            // chunks per super-chunk (second-level box)
   constexpr int kAcc = AccLayout<2>::kTotal;
   extern __shared__ __align__(16) unsigned char smem[];
   float2* tile = reinterpret_cast<float2*>(smem);                                   // sorted targets, padded
   float4* aabb = reinterpret_cast<float4*>(smem + lay.aabb_off);                    // per chunk {x0,y0,x1,y1}
-  float4* aabb2 = reinterpret_cast<float4*>(smem + lay.aabb2_off);                  // per super-chunk
   float2* sh_src = reinterpret_cast<float2*>(smem + lay.src_off);                   // sorted sources: read twice per iteration, so they live on chip
   uint16_t* sh_prev = reinterpret_cast<uint16_t*>(smem + lay.prev_off);             // last match (sorted target position) of every source
   double* sh_red = reinterpret_cast<double*>(smem + lay.red_off);                   // [waves][kAcc]
@@ -170,7 +167,6 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   const uint16_t* __restrict__ tidx = sc.tgt_index + ts;
   const bool box = (args.flags & kFlagNormalize) != 0;
   const int nchunks = (m + CHUNK - 1) / CHUNK;
-  const int nsuper = (nchunks + SUPER - 1) / SUPER;
 
   if (tid < 16) sh_T[tid] = args.init_T[(int64_t)16 * pair + tid];
   for (int j = tid; j < nchunks * CHUNK; j += blockDim.x) tile[j] = (j < m) ? sc.tgt_sorted[ts + j] : make_float2(kFar, kFar);
@@ -186,16 +182,6 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
     aabb[c] = make_float4(x0, y0, x1, y1);
   }
   __syncthreads();
-  for (int u = tid; u < nsuper; u += blockDim.x) {
-    float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
-    for (int k = 0; k < SUPER && u * SUPER + k < nchunks; ++k) {
-      const float4 b = aabb[u * SUPER + k];
-      x0 = fminf(x0, b.x); y0 = fminf(y0, b.y); x1 = fmaxf(x1, b.z); y1 = fmaxf(y1, b.w);
-    }
-    aabb2[u] = make_float4(x0, y0, x1, y1);
-  }
-  __syncthreads();
-
   StopState st;
   stop_init(st);
   double err_out = 0.0;
@@ -255,31 +241,30 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
         }
       }
 
-      // ---- sweep with two levels of wave-uniform skipping ---------------------------------------
+      // ---- sweep: 64 chunk boxes are tested at once, one per lane, against the wave's box and the wave's largest
+      // bound; the chunks that survive (a 64-bit ballot, walked with scalar bit operations) get a second look with
+      // every lane's OWN points and CURRENT bounds before they are evaluated.  (One box test per chunk with a
+      // compare → scalar branch each, two levels deep, spent a quarter of the kernel's instructions.)
       const float4* t4 = reinterpret_cast<const float4*>(tile);
-      for (int u = 0; u < nsuper; ++u) {
-        {
-          const float4 b = aabb2[u];
+      float wb = -INFINITY;
+#pragma unroll
+      for (int p = 0; p < P; ++p) wb = fmaxf(wb, best[p]);
+      wb = wave_max_f(wb);                                   // no lane can ask for a chunk farther than this from the wave's box
+      for (int c0 = 0; c0 < nchunks; c0 += 64) {
+        bool cand = false;
+        if (c0 + lane < nchunks) {
+          const float4 b = aabb[c0 + lane];
           const float dx = fmaxf(fmaxf(b.x - wx1, wx0 - b.z), 0.f);
           const float dy = fmaxf(fmaxf(b.y - wy1, wy0 - b.w), 0.f);
-          const float lb = __builtin_fmaf(dy, dy, dx * dx) * kPruneSafety;
-          bool need = false;
-#pragma unroll
-          for (int p = 0; p < P; ++p) need |= best[p] >= lb;
-          if (!__any(need)) continue;                      // none of these 128 targets matters to this wave
+          cand = wb >= __builtin_fmaf(dy, dy, dx * dx) * kPruneSafety;
         }
-        const int c_end = min(nchunks, (u + 1) * SUPER);
-        for (int c = u * SUPER; c < c_end; ++c) {
+        unsigned long long todo = __ballot(cand);
+        while (todo) {
+          const int c = c0 + __builtin_ctzll(todo);
+          todo &= todo - 1;
           const float4 b = aabb[c];
-          const float dx = fmaxf(fmaxf(b.x - wx1, wx0 - b.z), 0.f);
-          const float dy = fmaxf(fmaxf(b.y - wy1, wy0 - b.w), 0.f);
-          const float lb = __builtin_fmaf(dy, dy, dx * dx) * kPruneSafety;
-          bool need = false;
-#pragma unroll
-          for (int p = 0; p < P; ++p) need |= best[p] >= lb;
-          if (!__any(need)) continue;                      // nothing in this chunk can beat or tie any lane
-          // second look with every lane's OWN points: the sorted sources of a wave sit on a Morton curve
-          // that sometimes jumps across the cloud; the wave's box is then large, each point's reach is not
+          // the sorted sources of a wave sit on a Morton curve that sometimes jumps across the cloud; the wave's
+          // box is then large, each point's reach is not
           bool need_own = false;
 #pragma unroll
           for (int p = 0; p < P; ++p) {
@@ -287,7 +272,7 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
             const float oy = fmaxf(fmaxf(b.y - ay[p], ay[p] - b.w), 0.f);
             need_own |= best[p] >= __builtin_fmaf(oy, oy, ox * ox) * kPruneSafety;
           }
-          if (!__any(need_own)) continue;
+          if (!__any(need_own)) continue;                    // nothing in this chunk can beat or tie any lane
           float4 v[CHUNK / 2];
 #pragma unroll
           for (int k = 0; k < CHUNK / 2; ++k) v[k] = t4[c * (CHUNK / 2) + k];
@@ -321,7 +306,7 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int j0 = bchunk[p] * CHUNK;
-        float second = INFINITY;                             // second smallest distance of the chunk: equal to the smallest ⇔ two equally near targets
+        float sec2 = INFINITY;                               // second smallest distance of the chunk: equal to the smallest ⇔ two equally near targets
         bd[p] = INFINITY; pos[p] = j0;
 #pragma unroll
         for (int kk = 0; kk < CHUNK; ++kk) {
@@ -331,11 +316,11 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
           // all in vector registers: a per-element compare into a scalar mask (v_cmp → s_and → s_or chains) was measured
           // 1.5× slower for the whole kernel
           const bool lt = d < bd[p];
-          second = __builtin_amdgcn_fmed3f(bd[p], second, d);
+          sec2 = __builtin_amdgcn_fmed3f(bd[p], sec2, d);
           pos[p] = lt ? j0 + k : pos[p];
           bd[p] = lt ? d : bd[p];
         }
-        tie |= (second == bd[p]) && (bd[p] < INFINITY);
+        tie |= (sec2 == bd[p]) && (bd[p] < INFINITY);
       }
       // ---- equal minima (duplicate or equidistant points, in one chunk or in two): exhaustive pass, lowest ORIGINAL index wins --
       if (__any(tie)) {
@@ -446,19 +431,21 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // 2. iterate
-  int P = 2;
+  // sources per lane: a wave evaluates every chunk ANY of its 64·P sources needs, so big clouds run with one source per
+  // lane (smaller wave boxes; measured on 4096² problems: 24.9 ms at P = 1, 27.5 at P = 2, 36.3 at P = 4); LiDAR-sized
+  // problems (one pass either way) are 3 % faster with two
+  int P = max_src_n >= 2048 ? 1 : 2;
   if (const char* env = getenv("LSLAM_ICP_PRUNE_P")) P = atoi(env);
   if (P != 1 && P != 2 && P != 4) P = 2;
   int threads = (int)((((max_src_n + P - 1) / P + 63) / 64) * 64);
   if (threads < 64) threads = 64;
   if (threads > kIcpBatchMaxThreads) threads = kIcpBatchMaxThreads;      // more sources: several passes
   const int padded = (int)(((max_tgt_n + kPruneChunk - 1) / kPruneChunk) * kPruneChunk);
-  const int nchunks = padded / kPruneChunk, nsuper = (nchunks + kPruneSuper - 1) / kPruneSuper;
+  const int nchunks = padded / kPruneChunk;
   PruneLayout lay{};
   auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
   size_t off = (size_t)padded * sizeof(float2);
   lay.aabb_off = (uint32_t)off; off += (size_t)nchunks * sizeof(float4);
-  lay.aabb2_off = (uint32_t)off; off += (size_t)nsuper * sizeof(float4);
   if (getenv("LSLAM_PRUNE_SRC_GLOBAL")) lay.src_off = 0xffffffffu;
   else { lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(float2)); }
   lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));

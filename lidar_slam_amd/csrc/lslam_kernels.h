@@ -66,7 +66,7 @@ struct PruneScratch {                      // Morton-sorted copies: problem k ow
   float2* tgt_sorted; uint16_t* tgt_index;
   int64_t src_stride, tgt_stride;          // = max_src_n, max_tgt_n of the batch
 };
-struct PruneLayout { uint32_t aabb_off, aabb2_off, src_off, prev_off, red_off; unsigned* debug_counter; };
+struct PruneLayout { uint32_t aabb_off, src_off, prev_off, red_off; unsigned* debug_counter; };
 bool icp_pruned_supported(int dim, int64_t max_src_n, int64_t max_tgt_n);
 hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n,
                              hipStream_t stream);
