@@ -28,6 +28,8 @@
 // with the exact recipe.  If a third chunk is within τ (rare on random clouds; always on lattices or clouds
 // far from the origin) the wave falls back to the exact sweep — results are identical by construction.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "lslam_device.h"
 #include "lslam_kernels.h"
@@ -377,8 +379,10 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
           fall |= own && (!(b3[p] > lim) || !(Rt < 1e15f) || !(an < 1e15f));
         }
         f_tries++;
+        if (args.debug && lane == 0) atomicAdd(args.debug, 1u);
         if (__any(fall)) {
           f_fails++;
+          if (args.debug && lane == 0) atomicAdd(args.debug + 1, 1u);
         } else {
 #pragma unroll
           for (int p = 0; p < P; ++p) {
@@ -626,6 +630,14 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
   a.src_bytes = (a.tile_bytes + a.w_bytes + src_need <= budget && tune.src_in_lds != 2) || tune.src_in_lds == 1 ? (uint32_t)src_need : 0u;
   const size_t smem = a.tile_bytes + a.w_bytes + a.src_bytes + sizeof(double) * ((size_t)kIcpBatchMaxWaves * kAcc + 16) + 16;
   const Build build = small ? Build::kSmall : (filter ? Build::kFilter : Build::kBig);
+  static unsigned* dbg = nullptr;
+  if (getenv("LSLAM_DEBUG")) {
+    if (!dbg) (void)hipMalloc(&dbg, 8);
+    else { unsigned h[2] = {0, 0}; (void)hipMemcpy(h, dbg, 8, hipMemcpyDeviceToHost); fprintf(stderr, "[lslam] previous batch launch: %u filter passes, %u fell back to the exact sweep\n", h[0], h[1]); }
+    (void)hipMemset(dbg, 0, 8);
+    a.debug = dbg;
+    fprintf(stderr, "[lslam] icp_batch build %d (0 big, 1 small, 2 filter), P %d, %d threads, %zu B LDS\n", (int)build, P, threads, smem);
+  }
 
   if (dim == 2) {
     if (P == 1) return launch_one<2, 1>(a, S, threads, smem, build, stream);

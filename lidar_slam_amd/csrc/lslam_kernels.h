@@ -43,6 +43,7 @@ struct IcpBatchArgs {
   uint32_t tile_bytes;       // filled by the launcher
   uint32_t src_bytes;        // filled by the launcher: LDS reserved for the source cloud (0 = read it from memory)
   uint32_t w_bytes;          // filled by the launcher: LDS reserved for |t|² per target (planar filter build, else 0)
+  unsigned* debug;           // LSLAM_DEBUG: [0] filter passes attempted, [1] passes that fell back to the exact sweep (or nullptr)
 };
 
 struct IcpBatchTuning {

@@ -51,16 +51,23 @@ pair_op_kernel(PairOpArgs a) {
 // it varies by a few percent from device to device); bench.py prices them against this measurement
 // as well as against the 2.4 GHz datasheet peak.
 __global__ void __launch_bounds__(256) valu_probe_kernel(float* out, int iters, float seed) {
-  float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
-  const float b = 1.0001f, c = 0.5f;
+  // 64 independent v_fma_f32 per trip, written in assembly: in C++ the compiler either packs them (v_pk_fma_f32 issues
+  // at half the instruction rate) or chains them through one register (measured 4 cycles per instruction instead of 2)
+  float r = seed + threadIdx.x;
+  asm volatile("v_mov_b32 v8, %0\n v_mov_b32 v20, 0\n v_mov_b32 v21, 0\n v_mov_b32 v22, 0\n v_mov_b32 v23, 0\n"
+               "v_mov_b32 v24, 0\n v_mov_b32 v25, 0\n v_mov_b32 v26, 0\n v_mov_b32 v27, 0\n"
+               :: "v"(r) : "v8", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27");
   for (int i = 0; i < iters; ++i) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c); a2 = __builtin_fmaf(a2, b, c); a3 = __builtin_fmaf(a3, b, c);
-      a4 = __builtin_fmaf(a4, b, c); a5 = __builtin_fmaf(a5, b, c); a6 = __builtin_fmaf(a6, b, c); a7 = __builtin_fmaf(a7, b, c);
-    }
+#define LSLAM_FMA8 "v_fma_f32 v20, v8, 1.0, 0.5\n v_fma_f32 v21, v8, 1.0, 0.5\n v_fma_f32 v22, v8, 1.0, 0.5\n v_fma_f32 v23, v8, 1.0, 0.5\n" \
+                   "v_fma_f32 v24, v8, 1.0, 0.5\n v_fma_f32 v25, v8, 1.0, 0.5\n v_fma_f32 v26, v8, 1.0, 0.5\n v_fma_f32 v27, v8, 1.0, 0.5\n"
+    asm volatile(LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8
+                 ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27");
+#undef LSLAM_FMA8
   }
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+  float s;
+  asm volatile("v_add_f32 %0, v20, v21\n v_add_f32 %0, %0, v22\n v_add_f32 %0, %0, v23\n v_add_f32 %0, %0, v24\n"
+               "v_add_f32 %0, %0, v25\n v_add_f32 %0, %0, v26\n v_add_f32 %0, %0, v27\n" : "=v"(s));
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
 hipError_t run_valu_probe(float* d_scratch /*2048*256 floats*/, hipStream_t stream, double* lane_ops_per_s) {
