@@ -55,10 +55,14 @@ while time.time() < t_end:
     flat_t, to = pack_clouds([p[1] for p in probs])
     init = np.tile(np.eye(4), (len(probs), 1, 1))
     oracles = [c_oracle.run_icp(s, t, np.eye(4), epsilon=1e-12, max_iters=12, recipe="device") for s, t in probs]
-    for prune in (False, True):
+    # all pairs (build picked by size), exact pruning, and all pairs on the big build with the expanded-form filter at every size
+    for prune, variant in ((False, None), (True, None), (False, "1")):
+        if variant:
+            os.environ["LSLAM_ICP_VARIANT"] = variant
         r = icp_batch(flat_s, so, flat_t, to, init, epsilon=1e-12, max_iters=12, return_correspondences=True, prune=prune)
+        os.environ.pop("LSLAM_ICP_VARIANT", None)
         for k, o in enumerate(oracles):
-            bad += not same(f"batch prune={prune} dim={dim} n={probs[k][0].shape[0]} m={probs[k][1].shape[0]}", r.T[k], r.error[k],
+            bad += not same(f"batch prune={prune} variant={variant} dim={dim} n={probs[k][0].shape[0]} m={probs[k][1].shape[0]}", r.T[k], r.error[k],
                             r.iterations[k], r.correspondences[so[k]:so[k + 1]], o)
     for k, (s, t) in enumerate(probs[:6]):          # the same problems on the whole-chip path (fused below 8192 points)
         for prune in (_lib.ICP_ALL_PAIRS, _lib.ICP_PRUNE):
@@ -69,5 +73,5 @@ while time.time() < t_end:
             bad += not same(f"whole-chip prune={prune == _lib.ICP_PRUNE} dim={dim} n={s.shape[0]} m={t.shape[0]}", T, e[0], it[0], corr, oracles[k])
     rounds += 1; problems += len(probs)
     print(f"round {rounds}: {problems} problems so far, {bad} mismatches", flush=True)   # a silent long run is taken to be hung
-print(f"soak: {rounds} rounds, {problems} problems x (all-pairs, pruned) + {6 * rounds} x whole-chip (both): {bad} mismatches")
+print(f"soak: {rounds} rounds, {problems} problems x (all-pairs, pruned, filter build) + {6 * rounds} x whole-chip (both): {bad} mismatches")
 sys.exit(1 if bad else 0)
