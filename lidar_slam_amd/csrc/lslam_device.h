@@ -48,6 +48,103 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+
+// ---- the expanded-form FILTER of the all-pairs sweeps -----------------------
+//   g(a, t) = |t|² − 2 a·t  ( = |a − t|² − |a|² )      2 (planar) / 3 (3-D) v_fma per pair, |t|² kept beside the target
+// g is only a filter: its float32 error against the exact direct-difference distance is bounded, so the exact
+// winner lies in a chunk whose filter minimum is within τ of the best one.  Shared by the batched kernel
+// (lslam_icp_batch.hip) and the whole-chip search (lslam_icp_large.hip).
+template <int DIM> struct FilterPoint;
+template <> struct FilterPoint<2> { using type = float2; };
+template <> struct FilterPoint<3> { using type = float4; };
+
+constexpr int kFilterChunk = 32;
+constexpr int kFilterStep = 8;                 // targets per load group
+
+template <int DIM> struct FilterRegs;          // one load group in registers
+template <> struct FilterRegs<2> { float4 v[4], w[2]; };      // 8 × (x, y) + 8 × |t|²
+template <> struct FilterRegs<3> { float4 v[8]; };            // 8 × (x, y, z, |t|²)
+
+template <int DIM>
+__device__ __forceinline__ void filter_load(FilterRegs<DIM>& r, const typename FilterPoint<DIM>::type* tile, const float* wt, int step) {
+  if constexpr (DIM == 2) {
+    const float4* t4 = reinterpret_cast<const float4*>(tile) + step * 4;      // two points per 16 B
+    const float4* w4 = reinterpret_cast<const float4*>(wt) + step * 2;        // four |t|² per 16 B
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.v[k] = t4[k];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) r.w[k] = w4[k];
+  } else {
+    const float4* t4 = tile + step * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.v[k] = t4[k];
+  }
+}
+
+template <int DIM, int P>
+__device__ __forceinline__ void filter_eval(const FilterRegs<DIM>& r, const float (&na)[P][DIM], float (&m)[P]) {
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    if constexpr (DIM == 2) {
+      const float nx = na[p][0], ny = na[p][1];
+      const float g0 = __builtin_fmaf(r.v[0].x, nx, __builtin_fmaf(r.v[0].y, ny, r.w[0].x));
+      const float g1 = __builtin_fmaf(r.v[0].z, nx, __builtin_fmaf(r.v[0].w, ny, r.w[0].y));
+      const float g2 = __builtin_fmaf(r.v[1].x, nx, __builtin_fmaf(r.v[1].y, ny, r.w[0].z));
+      const float g3 = __builtin_fmaf(r.v[1].z, nx, __builtin_fmaf(r.v[1].w, ny, r.w[0].w));
+      const float g4 = __builtin_fmaf(r.v[2].x, nx, __builtin_fmaf(r.v[2].y, ny, r.w[1].x));
+      const float g5 = __builtin_fmaf(r.v[2].z, nx, __builtin_fmaf(r.v[2].w, ny, r.w[1].y));
+      const float g6 = __builtin_fmaf(r.v[3].x, nx, __builtin_fmaf(r.v[3].y, ny, r.w[1].z));
+      const float g7 = __builtin_fmaf(r.v[3].z, nx, __builtin_fmaf(r.v[3].w, ny, r.w[1].w));
+      float mm = fminf(fminf(g0, g1), m[p]);
+      mm = fminf(fminf(g2, g3), mm);
+      mm = fminf(fminf(g4, g5), mm);
+      m[p] = fminf(fminf(g6, g7), mm);
+    } else {
+      const float nx = na[p][0], ny = na[p][1], nz = na[p][2];
+      float mm = m[p];
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        const float g0 = __builtin_fmaf(r.v[k].x, nx, __builtin_fmaf(r.v[k].y, ny, __builtin_fmaf(r.v[k].z, nz, r.v[k].w)));
+        const float g1 = __builtin_fmaf(r.v[k + 1].x, nx, __builtin_fmaf(r.v[k + 1].y, ny, __builtin_fmaf(r.v[k + 1].z, nz, r.v[k + 1].w)));
+        mm = fminf(fminf(g0, g1), mm);
+      }
+      m[p] = mm;
+    }
+  }
+}
+
+
+// the three smallest chunk minima b1 ≤ b2 ≤ b3 and the chunk ids of the first two, updated with chunk c's minimum
+__device__ __forceinline__ void filter_track(float mc, int c, float& b1, float& b2, float& b3, int& i1, int& i2) {
+  // selects, not branches (the conditions are data-dependent per lane)
+  const bool lt1 = __builtin_unpredictable(mc < b1), lt2 = __builtin_unpredictable(mc < b2);
+  b3 = __builtin_amdgcn_fmed3f(b2, b3, mc);                  // b2 ≤ b3 holds: the median is the new third smallest
+  b2 = __builtin_amdgcn_fmed3f(b1, b2, mc);
+  b1 = lt1 ? mc : b1;
+  const int i2n = lt2 ? c : i2;
+  i2 = lt1 ? i1 : i2n;
+  i1 = lt1 ? c : i1;
+}
+
+// After the sweep: does the second chunk have to be re-evaluated (`two`), and is a third chunk (or an overflow risk)
+// in play so that the exact sweep must run instead (`third`)?  Rt ≥ the largest |t| swept.  Every comparison is
+// written so that a NaN sends the caller to the exact sweep.
+template <int DIM>
+__device__ __forceinline__ void filter_decide(const float (&a)[DIM], float Rt, float b1, float b2, float b3, bool& two, bool& third) {
+  constexpr float kU = 5.97e-8f;                             // > 2⁻²⁴
+  constexpr float kE = (DIM == 2 ? 4.5f : 6.5f) * kU;
+  float a2;
+  if constexpr (DIM == 2) a2 = __builtin_fmaf(a[1], a[1], a[0] * a[0]);
+  else a2 = __builtin_fmaf(a[2], a[2], __builtin_fmaf(a[1], a[1], a[0] * a[0]));
+  const float an = sqrtf(a2) * 1.0001f;
+  const float E = kE * Rt * (Rt + an);
+  const float d2 = fmaxf((b1 + a2) * 1.000001f + E + 3.f * kU * a2, 0.f);       // ≥ |a − t|² of the filter's winner
+  const float tau = (2.f * E + 9.f * kU * d2) * 1.001f + 1e-30f;
+  const float lim = b1 + tau;
+  two = !(b2 > lim);
+  third = !(b3 > lim) || !(Rt < 1e15f) || !(an < 1e15f);
+}
+
 // Accumulator slots of one (p, q) pair stream, in the order they are reduced.
 //   planar: n, Σp(2), Σq(2), Σpqᵀ(4), sse            = 10   (+4 bbox when normalising)
 //   3-D   : n, Σp(3), Σq(3), Σpqᵀ(9), sse            = 17   (+6 bbox)

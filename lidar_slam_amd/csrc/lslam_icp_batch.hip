@@ -124,61 +124,6 @@ __device__ __forceinline__ void sweep_tile(const typename TilePoint<DIM>::type* 
 // ---- the all-pairs FILTER sweep (expanded form) -------------------------------------------------
 // na[p] = −2·a[p]; per chunk of FCH targets: the minimum of g, then the update of the three smallest
 // chunk minima b1 ≤ b2 ≤ b3 and the chunk ids of the first two.
-constexpr int kFilterChunk = 32;
-constexpr int kFilterStep = 8;                 // targets per load group
-
-template <int DIM> struct FilterRegs;          // one load group in registers
-template <> struct FilterRegs<2> { float4 v[4], w[2]; };      // 8 × (x, y) + 8 × |t|²
-template <> struct FilterRegs<3> { float4 v[8]; };            // 8 × (x, y, z, |t|²)
-
-template <int DIM>
-__device__ __forceinline__ void filter_load(FilterRegs<DIM>& r, const typename TilePoint<DIM>::type* tile, const float* wt, int step) {
-  if constexpr (DIM == 2) {
-    const float4* t4 = reinterpret_cast<const float4*>(tile) + step * 4;      // two points per 16 B
-    const float4* w4 = reinterpret_cast<const float4*>(wt) + step * 2;        // four |t|² per 16 B
-#pragma unroll
-    for (int k = 0; k < 4; ++k) r.v[k] = t4[k];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) r.w[k] = w4[k];
-  } else {
-    const float4* t4 = tile + step * 8;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) r.v[k] = t4[k];
-  }
-}
-
-template <int DIM, int P>
-__device__ __forceinline__ void filter_eval(const FilterRegs<DIM>& r, const float (&na)[P][DIM], float (&m)[P]) {
-#pragma unroll
-  for (int p = 0; p < P; ++p) {
-    if constexpr (DIM == 2) {
-      const float nx = na[p][0], ny = na[p][1];
-      const float g0 = __builtin_fmaf(r.v[0].x, nx, __builtin_fmaf(r.v[0].y, ny, r.w[0].x));
-      const float g1 = __builtin_fmaf(r.v[0].z, nx, __builtin_fmaf(r.v[0].w, ny, r.w[0].y));
-      const float g2 = __builtin_fmaf(r.v[1].x, nx, __builtin_fmaf(r.v[1].y, ny, r.w[0].z));
-      const float g3 = __builtin_fmaf(r.v[1].z, nx, __builtin_fmaf(r.v[1].w, ny, r.w[0].w));
-      const float g4 = __builtin_fmaf(r.v[2].x, nx, __builtin_fmaf(r.v[2].y, ny, r.w[1].x));
-      const float g5 = __builtin_fmaf(r.v[2].z, nx, __builtin_fmaf(r.v[2].w, ny, r.w[1].y));
-      const float g6 = __builtin_fmaf(r.v[3].x, nx, __builtin_fmaf(r.v[3].y, ny, r.w[1].z));
-      const float g7 = __builtin_fmaf(r.v[3].z, nx, __builtin_fmaf(r.v[3].w, ny, r.w[1].w));
-      float mm = fminf(fminf(g0, g1), m[p]);
-      mm = fminf(fminf(g2, g3), mm);
-      mm = fminf(fminf(g4, g5), mm);
-      m[p] = fminf(fminf(g6, g7), mm);
-    } else {
-      const float nx = na[p][0], ny = na[p][1], nz = na[p][2];
-      float mm = m[p];
-#pragma unroll
-      for (int k = 0; k < 8; k += 2) {
-        const float g0 = __builtin_fmaf(r.v[k].x, nx, __builtin_fmaf(r.v[k].y, ny, __builtin_fmaf(r.v[k].z, nz, r.v[k].w)));
-        const float g1 = __builtin_fmaf(r.v[k + 1].x, nx, __builtin_fmaf(r.v[k + 1].y, ny, __builtin_fmaf(r.v[k + 1].z, nz, r.v[k + 1].w)));
-        mm = fminf(fminf(g0, g1), mm);
-      }
-      m[p] = mm;
-    }
-  }
-}
-
 // na[p] = −2·a[p]; per chunk of kFilterChunk targets: the minimum of g, then the update of the three smallest
 // chunk minima b1 ≤ b2 ≤ b3 and the chunk ids of the first two.  (Issuing a group's loads one group ahead of
 // its use — two register buffers held apart with scheduling barriers — was measured: no gain, 24 more VGPRs.)
@@ -199,17 +144,7 @@ __device__ __forceinline__ void filter_sweep(const typename TilePoint<DIM>::type
       filter_eval<DIM, P>(A, na, m);
     }
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const float mc = m[p];
-      // selects, not branches (the conditions are data-dependent per lane)
-      const bool lt1 = __builtin_unpredictable(mc < b1[p]), lt2 = __builtin_unpredictable(mc < b2[p]);
-      b3[p] = __builtin_amdgcn_fmed3f(b2[p], b3[p], mc);     // b2 ≤ b3 holds: the median is the new third smallest
-      b2[p] = __builtin_amdgcn_fmed3f(b1[p], b2[p], mc);
-      b1[p] = lt1 ? mc : b1[p];
-      const int i2n = lt2 ? c : i2[p];
-      i2[p] = lt1 ? i1[p] : i2n;
-      i1[p] = lt1 ? c : i1[p];
-    }
+    for (int p = 0; p < P; ++p) filter_track(m[p], c, b1[p], b2[p], b3[p], i1[p], i2[p]);
   }
 }
 
@@ -359,24 +294,12 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
         for (int p = 0; p < P; ++p)
 #pragma unroll
           for (int r = 0; r < DIM; ++r) a[p][r] = -0.5f * na[p][r];
-        // rounding-error bound of g against the exact distance (see the header comment and DESIGN.md §3.1c)
-        constexpr float kU = 5.97e-8f;                       // > 2⁻²⁴
-        constexpr float kE = (DIM == 2 ? 4.5f : 6.5f) * kU;
         bool two[P], fall = false;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          float a2;
-          if constexpr (DIM == 2) a2 = __builtin_fmaf(a[p][1], a[p][1], a[p][0] * a[p][0]);
-          else a2 = __builtin_fmaf(a[p][2], a[p][2], __builtin_fmaf(a[p][1], a[p][1], a[p][0] * a[p][0]));
-          const float an = sqrtf(a2) * 1.0001f;
-          const float E = kE * Rt * (Rt + an);
-          const float d2 = fmaxf((b1[p] + a2) * 1.000001f + E + 3.f * kU * a2, 0.f);       // ≥ |a − t|² of the filter's winner
-          const float tau = (2.f * E + 9.f * kU * d2) * 1.001f + 1e-30f;
-          const float lim = b1[p] + tau;
-          const bool own = base + tid * P + p < n;
-          two[p] = !(b2[p] > lim);
-          // a third chunk within the bound, or magnitudes where the filter could overflow: exact sweep instead
-          fall |= own && (!(b3[p] > lim) || !(Rt < 1e15f) || !(an < 1e15f));
+          bool third;
+          filter_decide<DIM>(a[p], Rt, b1[p], b2[p], b3[p], two[p], third);
+          fall |= (base + tid * P + p < n) && third;
         }
         f_tries++;
         if (args.debug && lane == 0) atomicAdd(args.debug, 1u);

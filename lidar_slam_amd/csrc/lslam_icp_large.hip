@@ -254,6 +254,137 @@ nn_tiled_kernel(NnArgs a) {
   }
 }
 
+// ---- the same search with the expanded-form filter in front of the exact recipe (3-D clouds) ------------------
+// Sweep: g = |t|² − 2a·t (3 v_fma + a minimum per pair instead of 3 v_sub, v_mul, 2 v_fmac + a minimum), |t|² in the
+// w of the LDS tile; per source the three smallest minima over chunks of 32 targets and the ids of the first two.
+// Then the exact recipe on the chunks within the rounding bound τ (lslam_device.h: filter_decide).  A split is ONE
+// tile here, so those chunks are still in LDS (gathering them back from global memory cost as much as the sweep:
+// 12-byte points, one cache line per lane and load); a wave in which a third chunk is within τ re-sweeps the tile
+// with the exact recipe (rare: a split holds 1/splits of the target's density).  The key written is the same exact
+// (d² bits, index) as nn_tiled_kernel writes.
+template <int P>
+__global__ void __launch_bounds__(kNnThreads)
+nn_tiled_filter_kernel(NnArgs a) {
+  constexpr int DIM = 3, CHUNK = NnChunk<3>::value, FCH = kFilterChunk;
+  extern __shared__ __align__(16) unsigned char smem[];
+  float4* tile = reinterpret_cast<float4*>(smem);
+  __shared__ int sh_wmax;
+
+  if (a.state && a.state->done) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+
+  double T[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) T[r][c] = a.state ? a.state->T[4 * r + c] : a.T[4 * r + c];
+
+  const int64_t base = (int64_t)blockIdx.x * (kNnThreads * P);
+  float na[P][DIM];                                           // −2 · transformed source
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int64_t i = base + (int64_t)p * kNnThreads + tid;
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (i < a.n) { x = a.src[3 * i]; y = a.src[3 * i + 1]; z = a.src[3 * i + 2]; }
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) na[p][r] = -2.f * (float)(T[r][0] * x + T[r][1] * y + T[r][2] * z + T[r][3]);     // icp.py:116
+  }
+
+  const int64_t first_pt = (int64_t)blockIdx.y * a.chunks_per_split * CHUNK;         // this split = one tile
+  const int cnt = (int)max((int64_t)0, min((int64_t)a.tile_points, a.m - first_pt));
+  unsigned long long* __restrict__ keys = a.keys + (int64_t)blockIdx.y * a.n;
+  const int padded = (cnt + FCH - 1) / FCH * FCH;
+
+  float wmax = 0.f;
+  if (tid == 0) sh_wmax = 0;
+  for (int j = tid; j < padded; j += kNnThreads) {
+    float4 v = make_float4(kFar, kFar, kFar, INFINITY);       // padding: g = +inf (an fma rounds once: never a NaN)
+    if (j < cnt) {
+      const int64_t g = first_pt + j;
+      v.x = a.tgt[3 * g]; v.y = a.tgt[3 * g + 1]; v.z = a.tgt[3 * g + 2];
+      v.w = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
+      wmax = fmaxf(wmax, v.w);
+    }
+    tile[j] = v;
+  }
+  __syncthreads();
+  // the largest |t|² of the split bounds the filter's rounding error
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+  if (lane == 0) atomicMax(&sh_wmax, __float_as_int(wmax));   // non-negative floats order like their bits
+
+  float b1[P], b2[P], b3[P];
+  int i1[P], i2[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) { b1[p] = b2[p] = b3[p] = INFINITY; i1[p] = 0; i2[p] = 0; }
+  for (int c = 0; c < padded / FCH; ++c) {
+    float m[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) m[p] = INFINITY;
+#pragma unroll 1
+    for (int h = 0; h < FCH / kFilterStep; ++h) {
+      FilterRegs<3> A;
+      filter_load<3>(A, tile, nullptr, c * (FCH / kFilterStep) + h);
+      filter_eval<3, P>(A, na, m);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) filter_track(m[p], c, b1[p], b2[p], b3[p], i1[p], i2[p]);
+  }
+  __syncthreads();                                            // every wave's maximum is in
+  const float Rt = sqrtf(__int_as_float(sh_wmax)) * 1.0001f;
+
+  float s[P][DIM];
+  bool two[P], fall = false;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) s[p][r] = -0.5f * na[p][r];      // exact
+    bool third;
+    filter_decide<3>(s[p], Rt, b1[p], b2[p], b3[p], two[p], third);
+    fall |= (base + (int64_t)p * kNnThreads + tid < a.n) && third;
+  }
+
+  // exact recipe: 64-bit key (distance bits, index inside the tile) — distances are non-negative floats, so one
+  // unsigned compare is the (distance, lowest index) rule
+  unsigned long long key[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) key[p] = kKeyInit;
+  auto eval = [&](int j, unsigned long long& k, const float (&pt)[DIM]) {
+    const float4 v = tile[j];
+    const float d = dist2(pt[0], pt[1], pt[2], v.x, v.y, v.z);
+    const unsigned long long cand = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
+    k = cand < k ? cand : k;
+  };
+  if (cnt > 0) {
+    if (__any(fall)) {
+      for (int j = 0; j < cnt; ++j)                           // wave-uniform address: a broadcast read per target
+#pragma unroll
+        for (int p = 0; p < P; ++p) eval(j, key[p], s[p]);
+    } else {
+      int rot = lane;
+      asm volatile("" : "+v"(rot));                           // opaque: the 32 rotated offsets are not worth 32 live registers
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+#pragma unroll 8
+        for (int kk = 0; kk < FCH; ++kk) eval(i1[p] * FCH + ((kk + rot) & (FCH - 1)), key[p], s[p]);   // rotated start: all chunks begin on the same banks
+        if (__any(two[p])) {
+          unsigned long long k2 = key[p];
+#pragma unroll 8
+          for (int kk = 0; kk < FCH; ++kk) eval(i2[p] * FCH + ((kk + rot) & (FCH - 1)), k2, s[p]);
+          key[p] = two[p] ? k2 : key[p];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int64_t i = base + (int64_t)p * kNnThreads + tid;
+    if (i >= a.n) continue;
+    // padding targets evaluate to +inf and never win against a real one; the index becomes global here
+    keys[i] = cnt > 0 ? key[p] + (unsigned long long)first_pt : kKeyInit;
+  }
+}
+
 // keys → (index, d²).  Used by the NN-only entry point.
 __global__ void nn_finalize_kernel(const unsigned long long* keys, int64_t n, int splits, int32_t* out_idx, float* out_d2) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -349,6 +480,11 @@ solve_kernel(SolveArgs a) {
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
+static bool nn_filter_enabled() {
+  const char* e = getenv("LSLAM_ICP_FILTER");
+  return !e || atoi(e) != 0;
+}
+
 NnGeometry nn_geometry(int dim, int64_t n, int64_t m) {
   NnGeometry g{};
   const int CHUNK = (dim == 2) ? NnChunk<2>::value : NnChunk<3>::value;
@@ -360,17 +496,33 @@ NnGeometry nn_geometry(int dim, int64_t n, int64_t m) {
   // a whole number of LDS tiles, a tile at least kNnTileMin points.
   int64_t want = (kNnTargetWorkgroups + sb - 1) / sb;
   if (want < 1) want = 1;
-  if (want > kNnMaxSplits) want = kNnMaxSplits;
   const int tile_max = (dim == 2) ? kNnTilePlanar : kNnTile3D;
-  int64_t tile = ((m + want - 1) / want + CHUNK - 1) / CHUNK * CHUNK;
   static const int tile_min = [] { const char* e = getenv("LSLAM_NN_TILE_MIN"); const int v = e ? atoi(e) : kNnTileMin; return v < 16 ? 16 : v; }();
+  g.grid_x = (unsigned)sb;
+  // 3-D, several source points per lane (the non-fused launches): the expanded-form filter search, whose split is ONE
+  // tile of whole filter chunks — as many splits as tiles (keys: 8 bytes per source and split)
+  if (dim == 3 && g.P > 1 && nn_filter_enabled()) {
+    int64_t tile = ((m + want - 1) / want + kFilterChunk - 1) / kFilterChunk * kFilterChunk;
+    if (tile < tile_min) tile = (tile_min + kFilterChunk - 1) / kFilterChunk * kFilterChunk;
+    if (tile > tile_max) tile = tile_max;
+    const int64_t splits = (m + tile - 1) / tile;
+    if (splits <= kNnMaxSplitsFilter) {
+      g.filter = true;
+      g.splits = (int)splits;
+      g.tile_points = (int)tile;
+      g.chunks_per_split = tile / CHUNK;
+      g.smem = (size_t)tile * pt_bytes;
+      return g;
+    }
+  }
+  if (want > kNnMaxSplits) want = kNnMaxSplits;
+  int64_t tile = ((m + want - 1) / want + CHUNK - 1) / CHUNK * CHUNK;
   if (tile < tile_min) tile = (tile_min + CHUNK - 1) / CHUNK * CHUNK;
   if (tile > tile_max) tile = tile_max;
   const int64_t tiles_total = (m + tile - 1) / tile;
   int64_t tiles_per_split = tiles_total / want;
   if (tiles_per_split < 1) tiles_per_split = 1;
   const int64_t splits = (tiles_total + tiles_per_split - 1) / tiles_per_split;
-  g.grid_x = (unsigned)sb;
   g.splits = (int)splits;
   g.tile_points = (int)tile;
   g.chunks_per_split = tiles_per_split * (tile / CHUNK);
@@ -390,7 +542,11 @@ hipError_t launch_nn(NnArgs a, int dim, const NnGeometry& g, hipStream_t stream)
     else if (g.P == 2) hipLaunchKernelGGL((nn_tiled_kernel<2, 2, false>), grid, block, g.smem, stream, a);
     else hipLaunchKernelGGL((nn_tiled_kernel<2, 4, false>), grid, block, g.smem, stream, a);
   } else {
+    // the expanded-form filter sweep is the default of the 3-D search with several points per lane
+    // (LSLAM_ICP_FILTER=0: direct-difference sweep); nn_geometry decides, the two kernels need different splits
     if (fuse) hipLaunchKernelGGL((nn_tiled_kernel<3, 1, true>), grid, block, g.smem, stream, a);
+    else if (g.filter && g.P == 2) hipLaunchKernelGGL((nn_tiled_filter_kernel<2>), grid, block, g.smem, stream, a);
+    else if (g.filter) hipLaunchKernelGGL((nn_tiled_filter_kernel<4>), grid, block, g.smem, stream, a);
     else if (g.P == 1) hipLaunchKernelGGL((nn_tiled_kernel<3, 1, false>), grid, block, g.smem, stream, a);
     else if (g.P == 2) hipLaunchKernelGGL((nn_tiled_kernel<3, 2, false>), grid, block, g.smem, stream, a);
     else hipLaunchKernelGGL((nn_tiled_kernel<3, 4, false>), grid, block, g.smem, stream, a);

@@ -86,6 +86,7 @@ constexpr int kNnTile3D = 2048;       // 32 KiB
 constexpr int kNnTileMin = 128;       // smallest tile worth a workgroup (small clouds: more splits)
 constexpr int kNnTargetWorkgroups = 2048;
 constexpr int kNnMaxSplits = 64;
+constexpr int kNnMaxSplitsFilter = 1024;   // filter search: one tile per split (8 bytes of key per source and split)
 constexpr int kMomThreads = 256;
 constexpr int kMomMaxBlocks = 1024;
 
@@ -122,6 +123,7 @@ struct NnGeometry {
   int tile_points;
   int64_t chunks_per_split;
   size_t smem;
+  bool filter;                   // 3-D: nn_tiled_filter_kernel (expanded-form sweep, one tile per split)
 };
 
 struct MomArgs {
