@@ -242,7 +242,7 @@ def main():
                          "pair_evals_per_s": pair_evals_per_launch / (kernel_ms * 1e-3),
                          "device_valu_probe_lane_ops_per_s": issue_rate,
                          "kernel_valu_instructions_per_pair_eval": prof.get("lane_ops_per_pair_eval"), "profile": prof.get("source"),
-                         "note": "float32 VALU-issue bound: the all-pairs sweep runs out of LDS (expanded form |t|^2 - 2a.t = 2 v_fma + 1 min per pair, "
+                         "peak_is": "fp32 vector FMA peak = the guide's dense f32 MFMA peak (157.3 TFLOP/s); no MFMA is used", "note": "float32 VALU-issue bound: the all-pairs sweep runs out of LDS (expanded form |t|^2 - 2a.t = 2 v_fma + 1 min per pair, "
                                  "then the exact recipe on the chunks the rounding bound cannot exclude); HBM sees only the compulsory bytes. "
                                  "peak = fp32 vector FMA peak; v_min3_f32 issues at half rate on gfx950 (profiles/r02/valu_probe2.txt), so 3 issue slots per pair is the floor of this form"},
             # the same launch priced against the HBM roof, as the bench contract words it (algorithmic bytes / duration): four orders away, not the binding roof
@@ -459,11 +459,11 @@ def other_config(name, a, torch, device, stream, timed):
         ms_p = _time(torch, run_pruned, 2, 3)
         out = {"workload": "C5 dense 3-D 100k x 100k, 20 forced iterations, whole chip", "ms": ms, "iterations": it,
                "iterations_per_sec": it / (ms * 1e-3), "pair_evals_per_sec": it * 1e10 / (ms * 1e-3),
-               "roofline": {"kernel": "nn_tiled_kernel<3,4> (+ moments_kernel<3>, solve_kernel<3> per iteration)", "bound": "valu",
+               "roofline": {"kernel": "nn_tiled_filter_kernel<4> (+ moments_kernel<3>, solve_kernel<3> per iteration)", "bound": "valu",
                             "achieved": it * 1e10 * 8 / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                             "frac": it * 1e10 * 8 / (ms * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
                             "hbm_compulsory_bytes_per_iteration": 12 * 2 * 100000 + 4 * 100000,
-                            "note": "8 algorithmic flop per 3-D pair evaluation; whole iteration (3 launches) timed, not the search kernel alone"},
+                            "note": "8 algorithmic flop per 3-D pair evaluation (expanded-form filter sweep: 3 v_fma + a minimum per pair, exact recipe on the chunks within the rounding bound); whole iteration (3 launches) timed, not the search kernel alone"},
                "default_search_strategy": {"what": "same 20 iterations, strategy left to the library (pruning above 1e9 pair evaluations per iteration: Morton sort + box hierarchy, exact results; the sort is inside the timed call)",
                           "ms": ms_p, "speedup": ms / ms_p, "max_abs_T_difference": float(np.abs(res["p"][0] - T).max())},
                "pose_err_vs_truth": float(np.abs(T - T_true).max())}
