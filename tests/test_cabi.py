@@ -96,3 +96,18 @@ def test_pose_chain_reproduces_reference_outputs_without_gpu():
     g = golden("se2_outputs20.npz")
     np.testing.assert_allclose(chain_poses(g["relative_poses_scan_matching"]), g["poses_scan_matching"], atol=1e-12)
     assert chain_poses(np.zeros((0, 3, 3))).tolist() == [[0.0, 0.0, 0.0]]
+
+
+def test_header_constants_match_the_python_binding():
+    """flag bits and status codes of include/lslam.h are the ones lidar_slam_amd/_lib.py passes and maps"""
+    from lidar_slam_amd import _lib
+    text = open(HEADER).read()
+    defs = {k: int(v.rstrip("u"), 0) for k, v in re.findall(r"#define\s+(LSLAM_[A-Z0-9_]+)\s+\(?(-?\d+u?)\)?", text)}
+    assert defs["LSLAM_ICP_NORMALIZE_ERROR"] == _lib.ICP_NORMALIZE_ERROR
+    assert defs["LSLAM_ICP_PRUNE"] == _lib.ICP_PRUNE and defs["LSLAM_ICP_ALL_PAIRS"] == _lib.ICP_ALL_PAIRS
+    assert _lib.search_flags(None) == 0 and _lib.search_flags(True) == defs["LSLAM_ICP_PRUNE"] and _lib.search_flags(False) == defs["LSLAM_ICP_ALL_PAIRS"]
+    for name, val in (("LSLAM_PRE_POLAR", _lib.PRE_POLAR), ("LSLAM_PRE_DBSCAN", _lib.PRE_DBSCAN), ("LSLAM_PRE_RADIAL", _lib.PRE_RADIAL)):
+        assert defs[name] == val
+    for name, val in (("LSLAM_OK", _lib.OK), ("LSLAM_ERR_BAD_ARG", _lib.ERR_BAD_ARG), ("LSLAM_ERR_EMPTY_TARGET", _lib.ERR_EMPTY_TARGET),
+                      ("LSLAM_ERR_NONFINITE", _lib.ERR_NONFINITE), ("LSLAM_ERR_HIP", _lib.ERR_HIP)):
+        assert defs[name] == val
