@@ -626,3 +626,49 @@ def test_whole_chip_filter_search_adversarial(icp, case, monkeypatch):
         got[flt] = (T.copy(), corr.copy())
     np.testing.assert_array_equal(got["1"][1], got["0"][1])
     np.testing.assert_allclose(got["1"][0], got["0"][0], atol=1e-5 if case == "far" else 1e-12)
+
+
+def test_device_entry_points_on_alternating_streams(icp):
+    """the thread's workspaces (sorted copies, key rows, iteration state) are reused from call to call; calls on different
+    streams are ordered by the library (an event per call), so interleaving streams changes nothing"""
+    import torch
+    from lidar_slam_amd.batch import icp_batch_dev, icp_large_dev
+    from lidar_slam_amd.synth import batch_c4
+    dev = torch.device("cuda", 0)
+    w = batch_c4(64, 1024, seed=3)
+    src = torch.from_numpy(w.src).to(dev); tgt = torch.from_numpy(w.tgt).to(dev)
+    off = torch.from_numpy(w.src_off).to(dev); init = torch.from_numpy(w.init_T).to(dev)
+    S = 64
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.current_stream(dev)]
+    rng = np.random.default_rng(0)
+    big_s = torch.from_numpy(rng.normal(size=(9000, 3)).astype(np.float32)).to(dev)
+    big_t = torch.from_numpy(rng.normal(size=(30000, 3)).astype(np.float32)).to(dev)
+    torch.cuda.synchronize()
+
+    def batch_on(stream, prune):
+        oT = torch.empty((S, 4, 4), dtype=torch.float64, device=dev); oe = torch.empty(S, dtype=torch.float64, device=dev)
+        oi = torch.empty(S, dtype=torch.int32, device=dev)
+        icp_batch_dev(src.data_ptr(), off.data_ptr(), tgt.data_ptr(), off.data_ptr(), 2, init.data_ptr(), S, 1024, 1024,
+                      oT.data_ptr(), oe.data_ptr(), oi.data_ptr(), None, epsilon=0.0, max_iters=5, stopping_thresh=0.0,
+                      stream=stream.cuda_stream, prune=prune)
+        return oT, oi
+
+    ref = {}
+    for prune in (False, True):
+        oT, oi = batch_on(streams[2], prune)
+        torch.cuda.synchronize()
+        ref[prune] = oT.cpu().numpy()
+    ref_large = icp_large_dev(big_s.data_ptr(), 9000, big_t.data_ptr(), 30000, 3, np.eye(4), epsilon=0.0, max_iters=3, stopping_thresh=0.0,
+                              stream=streams[2].cuda_stream, prune=False)[0]
+    outs = []
+    for k in range(12):
+        st = streams[k % 3]
+        prune = bool(k & 1)
+        outs.append((prune, batch_on(st, prune)[0]))
+        if k % 4 == 0:
+            T = icp_large_dev(big_s.data_ptr(), 9000, big_t.data_ptr(), 30000, 3, np.eye(4), epsilon=0.0, max_iters=3, stopping_thresh=0.0,
+                              stream=streams[(k + 1) % 3].cuda_stream, prune=False)[0]
+            np.testing.assert_array_equal(T, ref_large)
+    torch.cuda.synchronize()
+    for prune, oT in outs:
+        np.testing.assert_array_equal(oT.cpu().numpy(), ref[prune])
