@@ -506,7 +506,8 @@ NnGeometry nn_geometry(int dim, int64_t n, int64_t m) {
     if (tile < tile_min) tile = (tile_min + kFilterChunk - 1) / kFilterChunk * kFilterChunk;
     if (tile > tile_max) tile = tile_max;
     const int64_t splits = (m + tile - 1) / tile;
-    if (splits <= kNnMaxSplitsFilter) {
+    // one key row per split: keep the key workspace below 2 GiB (beyond that the multi-tile splits of the direct sweep)
+    if (splits <= kNnMaxSplitsFilter && (double)n * (double)splits * 8.0 <= 2147483648.0) {
       g.filter = true;
       g.splits = (int)splits;
       g.tile_points = (int)tile;
