@@ -10,8 +10,8 @@
 //   * every lane owns P source points in registers.  Per iteration: transform them with the
 //     current T (float64 → float32), then sweep the LDS tile with wave-uniform (broadcast)
 //     ds_read_b128: per CHUNK targets 4·CHUNK VALU ops for the distances (direct difference),
-//     CHUNK/2 v_min3 and three ops to record (min, chunk id) — ≈4.7 lane-ops per pair instead of
-//     the 7 of a per-pair compare/select argmin.  A fix-up pass re-evaluates only the winning
+//     CHUNK/2 v_min3 (half rate on gfx950: as dear as one v_min per pair) and three ops to record
+//     (min, chunk id) — 4.86 instructions, ≈ 5.4 issue slots per pair.  A fix-up pass re-evaluates only the winning
 //     chunk to recover the exact index (lowest index on ties);
 //   * float64 moments Σp, Σq, Σpqᵀ, Σ‖p−q‖² (+ joint bounding box) → wave64 shuffle reduction →
 //     LDS → lane 0 solves (closed form for planar scans, Jacobi SVD for 3-D), applies the
