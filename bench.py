@@ -28,7 +28,16 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_VECTOR_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CUs × 4 SIMD × 32 lanes × 2 flop × 2.4 GHz
 PEAK_HBM_TBS = 8.0
-HEADLINE_KERNEL = "icp_batch_filter_kernel<2,4>"
+HEADLINE_KERNEL = "icp_batch_filter_kernel<2,8>"      # what launch_icp_batch picks for 4096 problems of 4096 planar points
+
+
+def headline_kernel(S, P):
+    """the build launch_icp_batch (csrc/lslam_icp_batch.hip) picks for S all-pairs problems of P planar points"""
+    if P <= 2560:
+        return "icp_batch_small_kernel<2,*>"
+    if P > 8192:
+        return "icp_batch_kernel<2,4>"
+    return HEADLINE_KERNEL if (P >= 3584 and S >= 2048) else "icp_batch_filter_kernel<2,4>"
 
 
 def profile_figures(workload, kernel):
@@ -235,7 +244,7 @@ def main():
                        "pairs_per_gpu": S, "points": P, "iterations": I, "sharding": f"independent pairs over {world} GPU(s), all-gather of poses", "search": "all pairs (LSLAM_ICP_ALL_PAIRS)"},
             "scan_pairs_per_sec": world * S * a.steps / dt,
             "pair_evals_per_sec": world * pair_evals_per_launch * a.steps / dt,
-            "roofline": {"kernel": HEADLINE_KERNEL if (P > 2560 and P <= 8192) else "icp_batch_*", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS,
+            "roofline": {"kernel": headline_kernel(S, P), "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
                          "traffic": prof.get("hbm_bytes_per_launch") if (S, P, I) == (4096, 4096, 50) else None,
                          "kernel_ms": kernel_ms, "algorithmic_flop_per_pair_eval": 5,
@@ -246,7 +255,7 @@ def main():
                                  "then the exact recipe on the chunks the rounding bound cannot exclude); HBM sees only the compulsory bytes. "
                                  "peak = fp32 vector FMA peak; v_min3_f32 issues at half rate on gfx950 (profiles/r02/valu_probe2.txt), so 3 issue slots per pair is the floor of this form"},
             # the same launch priced against the HBM roof, as the bench contract words it (algorithmic bytes / duration): four orders away, not the binding roof
-            "roofline_hbm": {"kernel": HEADLINE_KERNEL, "bound": "hbm", "achieved": (2 * S * P * 8 + S * 2 * 128) / (kernel_ms * 1e-3) / 1e9,
+            "roofline_hbm": {"kernel": headline_kernel(S, P), "bound": "hbm", "achieved": (2 * S * P * 8 + S * 2 * 128) / (kernel_ms * 1e-3) / 1e9,
                              "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": (2 * S * P * 8 + S * 2 * 128) / (kernel_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
                              "traffic": prof.get("hbm_bytes_per_launch") if (S, P, I) == (4096, 4096, 50) else None,
                              "note": "algorithmic bytes = both clouds once + transforms in/out per problem, independent of the iteration count"},

@@ -114,6 +114,27 @@ __device__ __forceinline__ void filter_eval(const FilterRegs<DIM>& r, const floa
 }
 
 
+// planar, four targets per load group: for builds with 8 source points per lane (half the registers of a load group,
+// the same 80 vector instructions per group)
+struct FilterRegsPlanar4 { float4 v[2], w; };
+__device__ __forceinline__ void filter_load4(FilterRegsPlanar4& r, const float2* tile, const float* wt, int step) {
+  const float4* t4 = reinterpret_cast<const float4*>(tile) + step * 2;
+  r.v[0] = t4[0]; r.v[1] = t4[1];
+  r.w = reinterpret_cast<const float4*>(wt)[step];
+}
+template <int P>
+__device__ __forceinline__ void filter_eval4(const FilterRegsPlanar4& r, const float (&na)[P][2], float (&m)[P]) {
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const float nx = na[p][0], ny = na[p][1];
+    const float g0 = __builtin_fmaf(r.v[0].x, nx, __builtin_fmaf(r.v[0].y, ny, r.w.x));
+    const float g1 = __builtin_fmaf(r.v[0].z, nx, __builtin_fmaf(r.v[0].w, ny, r.w.y));
+    const float g2 = __builtin_fmaf(r.v[1].x, nx, __builtin_fmaf(r.v[1].y, ny, r.w.z));
+    const float g3 = __builtin_fmaf(r.v[1].z, nx, __builtin_fmaf(r.v[1].w, ny, r.w.w));
+    m[p] = fminf(fminf(g2, g3), fminf(fminf(g0, g1), m[p]));
+  }
+}
+
 // the three smallest chunk minima b1 ≤ b2 ≤ b3 and the chunk ids of the first two, updated with chunk c's minimum
 __device__ __forceinline__ void filter_track(float mc, int c, float& b1, float& b2, float& b3, int& i1, int& i2) {
   // selects, not branches (the conditions are data-dependent per lane)

@@ -137,11 +137,20 @@ __device__ __forceinline__ void filter_sweep(const typename TilePoint<DIM>::type
 #pragma unroll
     for (int p = 0; p < P; ++p) m[p] = INFINITY;
     // NOT unrolled: the compiler would hoist all 24 loads of a chunk to its top and spill
+    if constexpr (DIM == 2 && P == 8) {
 #pragma unroll 1
-    for (int h = 0; h < kGroups; ++h) {
-      FilterRegs<DIM> A;
-      filter_load<DIM>(A, tile, wt, c * kGroups + h);
-      filter_eval<DIM, P>(A, na, m);
+      for (int h = 0; h < 2 * kGroups; ++h) {                  // four targets per group: 80 vector instructions per 3 LDS reads
+        FilterRegsPlanar4 A;
+        filter_load4(A, tile, wt, c * 2 * kGroups + h);
+        filter_eval4<P>(A, na, m);
+      }
+    } else {
+#pragma unroll 1
+      for (int h = 0; h < kGroups; ++h) {
+        FilterRegs<DIM> A;
+        filter_load<DIM>(A, tile, wt, c * kGroups + h);
+        filter_eval<DIM, P>(A, na, m);
+      }
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) filter_track(m[p], c, b1[p], b2[p], b3[p], i1[p], i2[p]);
@@ -181,7 +190,11 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
   float* sh_src = reinterpret_cast<float*>(smem + args.tile_bytes + args.w_bytes);   // the source cloud, DIM floats per point
   double* sh_red = reinterpret_cast<double*>(smem + args.tile_bytes + args.w_bytes + args.src_bytes);   // [waves][kAcc]
   double* sh_T = sh_red + (size_t)kIcpBatchMaxWaves * kAcc;                   // current transform, 16
-  int* sh_flag = reinterpret_cast<int*>(sh_T + 16);                           // [0] stop, [1] bits of max |t|² (FILTER)
+  // loop state of run_icp (icp.py:163-181) and the last error: wave 0 is the only reader and writer, and the values are
+  // wave-uniform — in LDS they cost nothing, in registers they were spilled around the solve (stores in every iteration)
+  double* sh_err = sh_T + 16;
+  StopState* sh_stop = reinterpret_cast<StopState*>(sh_err + 1);
+  int* sh_flag = reinterpret_cast<int*>(sh_stop + 1);                         // [0] stop, [1] bits of max |t|² (FILTER)
 
   const int pair = blockIdx.x;
   const int tid = threadIdx.x;
@@ -244,9 +257,7 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
     Rt = sqrtf(__int_as_float(sh_flag[1])) * 1.0001f;
   }
 
-  StopState st;
-  stop_init(st);
-  double err_out = 0.0;
+  if (tid == 0) { StopState st0; stop_init(st0); *sh_stop = st0; *sh_err = 0.0; }       // read first after the barrier that precedes the solve
   const int src_per_pass = blockDim.x * P;
   int f_tries = 0, f_fails = 0;                                // wave-uniform: filter passes attempted / fallen back
 
@@ -452,12 +463,15 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) Tprev[i] = sh_T[i];
       matmul4(Tstep, Tprev, Tnew);                           // icp.py:119
-      err_out = error_from_moments(mo, box);                 // icp.py:120 (pre-update residual)
-      const bool stop = stop_after_iteration(st, err_out, args.epsilon, args.stopping_thresh, args.max_iters);
+      const double err = error_from_moments(mo, box);       // icp.py:120 (pre-update residual)
+      StopState st = *sh_stop;
+      const bool stop = stop_after_iteration(st, err, args.epsilon, args.stopping_thresh, args.max_iters);
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) sh_T[i] = Tnew[i];
         sh_flag[0] = stop ? 1 : 0;
+        *sh_stop = st;
+        *sh_err = err;
       }
     }
     __syncthreads();
@@ -466,8 +480,8 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
 
   if (tid < 16) args.out_T[(int64_t)16 * pair + tid] = sh_T[tid];
   if (tid == 0) {
-    args.out_err[pair] = err_out;
-    args.out_iters[pair] = st.executed;
+    args.out_err[pair] = *sh_err;
+    args.out_iters[pair] = sh_stop->executed;
   }
 }
 
@@ -519,7 +533,7 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
   // points per lane
   int P = tune.points_per_lane;
   if (P == 0) P = (max_src_n <= 512) ? 1 : ((max_src_n <= 2048) ? 2 : 4);
-  if (P != 1 && P != 2 && P != 4) return hipErrorInvalidValue;
+  if (P != 1 && P != 2 && P != 4 && !(P == 8 && dim == 2)) return hipErrorInvalidValue;
   int64_t lanes = (max_src_n + P - 1) / P;
   int threads = (int)(((lanes + kWave - 1) / kWave) * kWave);
   if (threads < kWave) threads = kWave;
@@ -538,6 +552,17 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
   cap = ((cap + 31) / 32) * 32;                              // a multiple of every chunk size
   // the expanded-form filter needs the whole target in LDS (one tile); it is the default of the big build
   const bool filter = !small && max_tgt_n <= cap && tune.filter != 2;
+  // Planar filter build, big clouds in big batches: EIGHT source points per lane in half as many lanes (80 vector
+  // instructions per 3 LDS reads instead of per 6) and, up to 4096 source points, two 8-wave workgroups per CU
+  // instead of one of 16.  It pays only while every CU always holds two problems (tools/p8_crossover.sh,
+  // profiles/r02/p8_crossover.txt: 194 vs 210 ms on C4, 49 vs 53 ms at 8192 points, but 12.5 vs 11.5 ms for 512
+  // problems and 15.5 vs 10.9 ms at 2600 points).
+  if (filter && dim == 2 && tune.points_per_lane == 0 && tune.threads == 0 && max_src_n >= 3584 && S >= 2048) {
+    P = 8;
+    lanes = (max_src_n + P - 1) / P;
+    threads = (int)(((lanes + kWave - 1) / kWave) * kWave);
+    if (threads > kIcpBatchMaxThreads) threads = kIcpBatchMaxThreads;
+  }
   const int pad = filter ? kFilterChunk : CHUNK;
   int64_t need = ((max_tgt_n + pad - 1) / pad) * pad;
   if (need < pad) need = pad;
@@ -548,10 +573,11 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
   const int kAcc = (dim == 2) ? AccLayout<2>::kTotal : AccLayout<3>::kTotal;
   // keep the source cloud in LDS as well: the small build while four workgroups still fit a CU; the big build
   // (one workgroup per CU for its 128 VGPRs × up to 16 waves) while the whole workgroup stays below 128 KiB
-  const size_t budget = small ? 36 * 1024 : 128 * 1024;
+  // (… or, for the 8-wave workgroups of the P = 8 build, while two of them fit a CU)
+  const size_t budget = small ? 36 * 1024 : (threads <= 512 ? 78 * 1024 : 128 * 1024);
   const size_t src_need = (((size_t)max_src_n * dim * sizeof(float)) + 15) & ~(size_t)15;
   a.src_bytes = (a.tile_bytes + a.w_bytes + src_need <= budget && tune.src_in_lds != 2) || tune.src_in_lds == 1 ? (uint32_t)src_need : 0u;
-  const size_t smem = a.tile_bytes + a.w_bytes + a.src_bytes + sizeof(double) * ((size_t)kIcpBatchMaxWaves * kAcc + 16) + 16;
+  const size_t smem = a.tile_bytes + a.w_bytes + a.src_bytes + sizeof(double) * ((size_t)kIcpBatchMaxWaves * kAcc + 16 + 1) + sizeof(StopState) + 16;
   const Build build = small ? Build::kSmall : (filter ? Build::kFilter : Build::kBig);
   static unsigned* dbg = nullptr;
   if (getenv("LSLAM_DEBUG")) {
@@ -565,6 +591,7 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
   if (dim == 2) {
     if (P == 1) return launch_one<2, 1>(a, S, threads, smem, build, stream);
     if (P == 2) return launch_one<2, 2>(a, S, threads, smem, build, stream);
+    if (P == 8) return launch_one<2, 8>(a, S, threads, smem, build, stream);      // experiment knob (LSLAM_ICP_POINTS_PER_LANE=8)
     return launch_one<2, 4>(a, S, threads, smem, build, stream);
   }
   if (P == 1) return launch_one<3, 1>(a, S, threads, smem, build, stream);

@@ -154,7 +154,10 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   uint16_t* sh_prev = reinterpret_cast<uint16_t*>(smem + lay.prev_off);             // last match (sorted target position) of every source
   double* sh_red = reinterpret_cast<double*>(smem + lay.red_off);                   // [waves][kAcc]
   double* sh_T = sh_red + (size_t)kIcpBatchMaxWaves * kAcc;
-  int* sh_flag = reinterpret_cast<int*>(sh_T + 16);
+  // loop state and last error in LDS (wave 0 only, wave-uniform): in registers they were spilled around the solve
+  double* sh_err = sh_T + 16;
+  StopState* sh_stop = reinterpret_cast<StopState*>(sh_err + 1);
+  int* sh_flag = reinterpret_cast<int*>(sh_stop + 1);
 
   const int pair = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -182,9 +185,7 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
     aabb[c] = make_float4(x0, y0, x1, y1);
   }
   __syncthreads();
-  StopState st;
-  stop_init(st);
-  double err_out = 0.0;
+  if (tid == 0) { StopState st0; stop_init(st0); *sh_stop = st0; *sh_err = 0.0; }       // read first after the barrier that precedes the solve
   const int per_pass = blockDim.x * P;
   const int passes = n > 0 ? (n + per_pass - 1) / per_pass : 1;
 
@@ -395,12 +396,15 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) Tprev[i] = sh_T[i];
       matmul4(Tstep, Tprev, Tnew);
-      err_out = error_from_moments(mo, box);
-      const bool stop = stop_after_iteration(st, err_out, args.epsilon, args.stopping_thresh, args.max_iters);
+      const double err = error_from_moments(mo, box);
+      StopState st = *sh_stop;
+      const bool stop = stop_after_iteration(st, err, args.epsilon, args.stopping_thresh, args.max_iters);
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) sh_T[i] = Tnew[i];
         sh_flag[0] = stop ? 1 : 0;
+        *sh_stop = st;
+        *sh_err = err;
       }
     }
     __syncthreads();
@@ -409,8 +413,8 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
 
   if (tid < 16) args.out_T[(int64_t)16 * pair + tid] = sh_T[tid];
   if (tid == 0) {
-    args.out_err[pair] = err_out;
-    args.out_iters[pair] = st.executed;
+    args.out_err[pair] = *sh_err;
+    args.out_iters[pair] = sh_stop->executed;
   }
   // correspondences of the LAST iteration (icp.py:117, 187-189), in the caller's numbering
   if (args.out_corr)
@@ -450,7 +454,7 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   else { lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(float2)); }
   lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));
   lay.red_off = (uint32_t)off;
-  const size_t smem = off + sizeof(double) * ((size_t)kIcpBatchMaxWaves * AccLayout<2>::kTotal + 16) + 16;
+  const size_t smem = off + sizeof(double) * ((size_t)kIcpBatchMaxWaves * AccLayout<2>::kTotal + 16 + 1) + sizeof(StopState) + 16;
   auto launch = [&](auto kernel) -> hipError_t {
     if (smem > 48 * 1024) {
       hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -521,14 +521,17 @@ def _oracle_check(r, srcs, tgts, so, init, **kw):
 
 
 @pytest.mark.parametrize("dim", [2, 3])
-@pytest.mark.parametrize("ppl", ["1", "2", "4"])
+@pytest.mark.parametrize("ppl", ["1", "2", "4", "8", "auto"])
 def test_filter_sweep_gives_the_exact_answers(icp, dim, ppl, monkeypatch):
     """the big build's expanded-form filter (|t|² − 2a·t, then the exact recipe on the chunks within the rounding
     bound) against the C oracle's exact device recipe: random clouds at several scales, duplicates, clouds far from
     the origin (bound too loose: the wave must fall back), tiny and ragged sizes — and against the same build with the filter off"""
     from lidar_slam_amd.batch import icp_batch, pack_clouds
+    if ppl == "8" and dim == 3:
+        pytest.skip("eight points per lane exist for the planar build only")
     monkeypatch.setenv("LSLAM_ICP_VARIANT", "1")            # the big build whatever the size
-    monkeypatch.setenv("LSLAM_ICP_POINTS_PER_LANE", ppl)
+    if ppl != "auto":                                        # auto: the launcher's own choice (8 for big planar clouds)
+        monkeypatch.setenv("LSLAM_ICP_POINTS_PER_LANE", ppl)
     rng = np.random.default_rng(7000 + dim)
     sizes = [(3000, 4000), (8, 6), (70, 33), (4096, 4096), (1500, 31), (1000, 32), (2000, 2049), (640, 3000), (1300, 700)]
     if dim == 3:
@@ -553,7 +556,7 @@ def test_filter_sweep_gives_the_exact_answers(icp, dim, ppl, monkeypatch):
     e = icp_batch(fs, so, ft, to, I, return_correspondences=True, prune=False, **kw)
     np.testing.assert_array_equal(r.correspondences, e.correspondences)
     np.testing.assert_array_equal(r.iterations, e.iterations)
-    np.testing.assert_array_equal(r.T, e.T)                  # same pairs, same float64 summation order: identical bits
+    np.testing.assert_allclose(r.T, e.T, rtol=0, atol=0 if ppl != "auto" else 1e-11)   # same pairs and (same P) the same float64 summation order: identical bits
 
 
 def test_filter_sweep_on_lattices_and_collapsed_clouds(icp, monkeypatch):

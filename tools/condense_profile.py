@@ -50,7 +50,7 @@ out = {}
 fetch, _ = counters("pmc_fetch")
 write, _ = counters("pmc_write")
 sq, dur = counters("pmc_sq")
-for tag, needle in (("c4", "icp_batch_filter_kernel<2, 4>"), ("c4_default_search_strategy", "icp_pruned_kernel<1>"), ("c4_sort", "icp_sort_kernel")):
+for tag, needle in (("c4", "icp_batch_filter_kernel<2, 8>"), ("c4_default_search_strategy", "icp_pruned_kernel<1>"), ("c4_sort", "icp_sort_kernel")):
     kf, kw, ks = pick(fetch, needle), pick(write, needle), pick(sq, needle)
     if not (kf and kw and ks):
         continue
