@@ -39,8 +39,23 @@ def problem(dim):
     return src, tgt
 
 
-def same(tag, T, e, it, corr, oracle):
+undefined = 0
+
+
+def rank_one(tgt, corr):
+    """the matched targets are collinear (or one point): Kabsch's rotation is not unique there and the reference's answer
+    depends on LAPACK's null-space basis — parity is undefined, only correspondences / error are compared"""
+    q = np.asarray(tgt, np.float64)[np.asarray(corr)]
+    sv = np.linalg.svd(q - q.mean(0), compute_uv=False)
+    return sv.size < 2 or sv[1] <= 1e-9 * max(sv[0], 1e-300)
+
+
+def same(tag, T, e, it, corr, oracle, tgt=None):
+    global undefined
     To, eo, co, ito = oracle
+    if tgt is not None and it == ito and np.array_equal(corr, co) and abs(e - eo) <= 1e-9 * abs(eo) + 1e-18 and rank_one(tgt, co):
+        undefined += 1
+        return True
     ok = it == ito and np.array_equal(corr, co) and np.abs(T - To).max() < 1e-9 and abs(e - eo) <= 1e-9 * abs(eo) + 1e-18
     if not ok:
         print("MISMATCH", tag, "iterations", it, ito, "corr equal", np.array_equal(corr, co), "dT", np.abs(T - To).max(), "err", e, eo)
@@ -63,15 +78,15 @@ while time.time() < t_end:
         os.environ.pop("LSLAM_ICP_VARIANT", None)
         for k, o in enumerate(oracles):
             bad += not same(f"batch prune={prune} variant={variant} dim={dim} n={probs[k][0].shape[0]} m={probs[k][1].shape[0]}", r.T[k], r.error[k],
-                            r.iterations[k], r.correspondences[so[k]:so[k + 1]], o)
+                            r.iterations[k], r.correspondences[so[k]:so[k + 1]], o, probs[k][1])
     for k, (s, t) in enumerate(probs[:6]):          # the same problems on the whole-chip path (fused below 8192 points)
         for prune in (_lib.ICP_ALL_PAIRS, _lib.ICP_PRUNE):
             s32, t32 = np.ascontiguousarray(s, np.float32), np.ascontiguousarray(t, np.float32)
             T = np.empty((4, 4)); e = np.empty(1); it = np.empty(1, np.int32); corr = np.empty(s.shape[0], np.int32)
             check(lib().lslam_icp_large(ptr(s32), s.shape[0], ptr(t32), t.shape[0], dim, ptr(np.eye(4)), 1e-12, 1e-4, 12, prune,
                                         ptr(T), ptr(e), ptr(it), ptr(corr), 0))
-            bad += not same(f"whole-chip prune={prune == _lib.ICP_PRUNE} dim={dim} n={s.shape[0]} m={t.shape[0]}", T, e[0], it[0], corr, oracles[k])
+            bad += not same(f"whole-chip prune={prune == _lib.ICP_PRUNE} dim={dim} n={s.shape[0]} m={t.shape[0]}", T, e[0], it[0], corr, oracles[k], t)
     rounds += 1; problems += len(probs)
     print(f"round {rounds}: {problems} problems so far, {bad} mismatches", flush=True)   # a silent long run is taken to be hung
-print(f"soak: {rounds} rounds, {problems} problems x (all-pairs, pruned, filter build) + {6 * rounds} x whole-chip (both): {bad} mismatches")
+print(f"soak: {rounds} rounds, {problems} problems x (all-pairs, pruned, filter build) + {6 * rounds} x whole-chip (both): {bad} mismatches ({undefined} comparisons on rank-one matches skipped: parity undefined)")
 sys.exit(1 if bad else 0)
