@@ -675,3 +675,60 @@ def test_device_entry_points_on_alternating_streams(icp):
     torch.cuda.synchronize()
     for prune, oT in outs:
         np.testing.assert_array_equal(oT.cpu().numpy(), ref[prune])
+
+
+def test_headline_batch_shape_eight_points_per_lane(icp, monkeypatch):
+    """2048 problems of 4096 x 4096 planar points all pairs: the launcher's own choice there is the filter build with
+    EIGHT source points per lane in 8-wave workgroups (bench.py's headline kernel).  Sampled problems equal the C oracle's
+    exact recipe; the whole batch equals the four-points-per-lane build."""
+    from lidar_slam_amd.batch import icp_batch
+    from lidar_slam_amd.synth import batch_c4
+    from oracle import c_oracle
+    S = 2048
+    w = batch_c4(S, 4096, seed=9)
+    kw = dict(epsilon=1e-3, return_correspondences=True, prune=False)
+    r = icp_batch(w.src, w.src_off, w.tgt, w.tgt_off, w.init_T, **kw)
+    for k in (0, 777, S - 1):
+        sl = slice(k * 4096, (k + 1) * 4096)
+        To, eo, co, ito = c_oracle.run_icp(w.src[sl].astype(np.float64), w.tgt[sl].astype(np.float64), w.init_T[k], epsilon=1e-3, recipe="device")
+        assert r.iterations[k] == ito
+        np.testing.assert_array_equal(r.correspondences[sl], co)
+        np.testing.assert_allclose(r.T[k], To, atol=1e-9)
+    monkeypatch.setenv("LSLAM_ICP_POINTS_PER_LANE", "4")
+    r4 = icp_batch(w.src, w.src_off, w.tgt, w.tgt_off, w.init_T, **kw)
+    np.testing.assert_array_equal(r.iterations, r4.iterations)
+    np.testing.assert_array_equal(r.correspondences, r4.correspondences)
+    np.testing.assert_allclose(r.T, r4.T, atol=1e-11)
+    err_t = np.abs(r.T[:, :2, 3] - w.true_T[:, :2, 3]).max()
+    assert err_t < 2e-3, err_t                                        # 1 cm noise on 4096 points
+
+
+@pytest.mark.parametrize("strategy", ["filter", "direct", "pruned"])
+def test_full_size_dense_3d_identity_search(icp, strategy, monkeypatch):
+    """BASELINE's 100k x 100k 3-D size through a size-independent property: every point of a cloud is its own nearest
+    neighbour in that cloud, at distance exactly 0 — on the filter search, the direct-difference search and the pruned
+    search; and one ICP iteration from the identity leaves the identity."""
+    import torch
+    from lidar_slam_amd.batch import icp_large_dev, nn_dev
+    from lidar_slam_amd.synth import cloud_c5
+    _, tgt, _, _ = cloud_c5()
+    assert tgt.shape == (100_000, 3)
+    assert np.unique(tgt, axis=0).shape[0] == tgt.shape[0]             # no duplicate points: the identity is the unique answer
+    d_t = torch.from_numpy(tgt).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    if strategy == "direct":
+        monkeypatch.setenv("LSLAM_ICP_FILTER", "0")
+    if strategy != "pruned":
+        idx = torch.empty(tgt.shape[0], dtype=torch.int32, device="cuda")
+        d2 = torch.empty(tgt.shape[0], dtype=torch.float32, device="cuda")
+        nn_dev(d_t.data_ptr(), tgt.shape[0], d_t.data_ptr(), tgt.shape[0], 3, None, idx.data_ptr(), d2.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(idx.cpu().numpy(), np.arange(tgt.shape[0], dtype=np.int32))
+        assert float(d2.max().item()) == 0.0
+    corr = torch.empty(tgt.shape[0], dtype=torch.int32, device="cuda")
+    T, err, it = icp_large_dev(d_t.data_ptr(), tgt.shape[0], d_t.data_ptr(), tgt.shape[0], 3, np.eye(4), epsilon=0.0, max_iters=0,
+                               stopping_thresh=0.0, d_out_corr=corr.data_ptr(), stream=st, prune=(strategy == "pruned"))
+    torch.cuda.synchronize()
+    assert it == 1 and err == 0.0
+    np.testing.assert_array_equal(corr.cpu().numpy(), np.arange(tgt.shape[0], dtype=np.int32))
+    np.testing.assert_allclose(T, np.eye(4), atol=1e-12)
