@@ -258,7 +258,14 @@ def main():
             "roofline_hbm": {"kernel": headline_kernel(S, P), "bound": "hbm", "achieved": (2 * S * P * 8 + S * 2 * 128) / (kernel_ms * 1e-3) / 1e9,
                              "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": (2 * S * P * 8 + S * 2 * 128) / (kernel_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
                              "traffic": prof.get("hbm_bytes_per_launch") if (S, P, I) == (4096, 4096, 50) else None,
-                             "note": "algorithmic bytes = both clouds once + transforms in/out per problem, independent of the iteration count"},
+                             "measured_GBps": (prof.get("hbm_bytes_per_launch") or 0) / (kernel_ms * 1e-3) / 1e9 if prof.get("hbm_bytes_per_launch") else None,
+                             "measured_frac": (prof.get("hbm_bytes_per_launch") or 0) / (kernel_ms * 1e-3) / 1e12 / PEAK_HBM_TBS if prof.get("hbm_bytes_per_launch") else None,
+                             "note": "algorithmic bytes = both clouds once + transforms in/out per problem, independent of the iteration count; measured_* = PMC traffic of the committed profile over this run's kernel time"},
+            # SURVEY 8(d)'s third figure, kept apart from the roofline objects because it is NOT a fraction of anything the kernel does:
+            # the bytes a sweep with no on-chip reuse would move (4d per pair evaluation).  It only says what LDS tiling removed.
+            "untiled_traffic_equivalent": {"bytes_per_pair_eval": 8, "TBps": pair_evals_per_launch * 8 / (kernel_ms * 1e-3) / 1e12,
+                                           "times_hbm_peak": pair_evals_per_launch * 8 / (kernel_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                                           "note": "counterfactual, not a roofline: no kernel here moves these bytes"},
         }
         if rank == 0 and world == 1:
             # the same batch as the library runs it when the caller does not force a strategy: exact pruning (identical correspondences)
