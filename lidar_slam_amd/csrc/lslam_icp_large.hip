@@ -254,20 +254,22 @@ nn_tiled_kernel(NnArgs a) {
   }
 }
 
-// ---- the same search with the expanded-form filter in front of the exact recipe (3-D clouds) ------------------
-// Sweep: g = |t|² − 2a·t (3 v_fma + a minimum per pair instead of 3 v_sub, v_mul, 2 v_fmac + a minimum), |t|² in the
-// w of the LDS tile; per source the three smallest minima over chunks of 32 targets and the ids of the first two.
-// Then the exact recipe on the chunks within the rounding bound τ (lslam_device.h: filter_decide).  A split is ONE
-// tile here, so those chunks are still in LDS (gathering them back from global memory cost as much as the sweep:
-// 12-byte points, one cache line per lane and load); a wave in which a third chunk is within τ re-sweeps the tile
-// with the exact recipe (rare: a split holds 1/splits of the target's density).  The key written is the same exact
-// (d² bits, index) as nn_tiled_kernel writes.
-template <int P>
+// ---- the same search with the expanded-form filter in front of the exact recipe ------------------------------
+// Sweep: g = |t|² − 2a·t (2 / 3 v_fma + a minimum per pair instead of the direct difference), |t|² beside the target
+// in LDS (planar: a float array after the tile; 3-D: the w of the float4); per source the three smallest minima over
+// chunks of 32 targets and the ids of the first two.  Then the exact recipe on the chunks within the rounding bound τ
+// (lslam_device.h: filter_decide).  A split is ONE tile here, so those chunks are still in LDS (gathering them back
+// from global memory cost as much as the sweep: 12-byte points, one cache line per lane and load); a wave in which a
+// third chunk is within τ re-sweeps the tile with the exact recipe (rare: a split holds 1/splits of the target's
+// density).  The key written is the same exact (d² bits, index) as nn_tiled_kernel writes.
+template <int DIM, int P>
 __global__ void __launch_bounds__(kNnThreads)
 nn_tiled_filter_kernel(NnArgs a) {
-  constexpr int DIM = 3, CHUNK = NnChunk<3>::value, FCH = kFilterChunk;
+  constexpr int CHUNK = NnChunk<DIM>::value, FCH = kFilterChunk;
+  using TP = typename FilterPoint<DIM>::type;
   extern __shared__ __align__(16) unsigned char smem[];
-  float4* tile = reinterpret_cast<float4*>(smem);
+  TP* tile = reinterpret_cast<TP*>(smem);
+  float* wt = reinterpret_cast<float*>(smem + (size_t)a.tile_points * sizeof(TP));   // planar only
   __shared__ int sh_wmax;
 
   if (a.state && a.state->done) return;
@@ -285,9 +287,16 @@ nn_tiled_filter_kernel(NnArgs a) {
   for (int p = 0; p < P; ++p) {
     const int64_t i = base + (int64_t)p * kNnThreads + tid;
     double x = 0.0, y = 0.0, z = 0.0;
-    if (i < a.n) { x = a.src[3 * i]; y = a.src[3 * i + 1]; z = a.src[3 * i + 2]; }
+    if (i < a.n) {
+      x = a.src[DIM * i]; y = a.src[DIM * i + 1];
+      if constexpr (DIM == 3) z = a.src[DIM * i + 2];
+    }
 #pragma unroll
-    for (int r = 0; r < DIM; ++r) na[p][r] = -2.f * (float)(T[r][0] * x + T[r][1] * y + T[r][2] * z + T[r][3]);     // icp.py:116
+    for (int r = 0; r < DIM; ++r) {                           // icp.py:116
+      double v = T[r][0] * x + T[r][1] * y + T[r][3];
+      if constexpr (DIM == 3) v += T[r][2] * z;
+      na[p][r] = -2.f * (float)v;
+    }
   }
 
   const int64_t first_pt = (int64_t)blockIdx.y * a.chunks_per_split * CHUNK;         // this split = one tile
@@ -298,14 +307,23 @@ nn_tiled_filter_kernel(NnArgs a) {
   float wmax = 0.f;
   if (tid == 0) sh_wmax = 0;
   for (int j = tid; j < padded; j += kNnThreads) {
-    float4 v = make_float4(kFar, kFar, kFar, INFINITY);       // padding: g = +inf (an fma rounds once: never a NaN)
-    if (j < cnt) {
-      const int64_t g = first_pt + j;
-      v.x = a.tgt[3 * g]; v.y = a.tgt[3 * g + 1]; v.z = a.tgt[3 * g + 2];
-      v.w = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
-      wmax = fmaxf(wmax, v.w);
+    // padding: far coordinates (exact recipe → +inf) and |t|² = +inf (filter → +inf; an fma rounds once: never a NaN)
+    float w = INFINITY;
+    const int64_t g = first_pt + j;
+    if constexpr (DIM == 2) {
+      float2 v = make_float2(kFar, kFar);
+      if (j < cnt) { v = *reinterpret_cast<const float2*>(a.tgt + 2 * g); w = __builtin_fmaf(v.y, v.y, v.x * v.x); wmax = fmaxf(wmax, w); }
+      tile[j] = v;
+      wt[j] = w;
+    } else {
+      float4 v = make_float4(kFar, kFar, kFar, INFINITY);
+      if (j < cnt) {
+        v.x = a.tgt[3 * g]; v.y = a.tgt[3 * g + 1]; v.z = a.tgt[3 * g + 2];
+        v.w = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
+        wmax = fmaxf(wmax, v.w);
+      }
+      tile[j] = v;
     }
-    tile[j] = v;
   }
   __syncthreads();
   // the largest |t|² of the split bounds the filter's rounding error
@@ -323,9 +341,9 @@ nn_tiled_filter_kernel(NnArgs a) {
     for (int p = 0; p < P; ++p) m[p] = INFINITY;
 #pragma unroll 1
     for (int h = 0; h < FCH / kFilterStep; ++h) {
-      FilterRegs<3> A;
-      filter_load<3>(A, tile, nullptr, c * (FCH / kFilterStep) + h);
-      filter_eval<3, P>(A, na, m);
+      FilterRegs<DIM> A;
+      filter_load<DIM>(A, tile, wt, c * (FCH / kFilterStep) + h);
+      filter_eval<DIM, P>(A, na, m);
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) filter_track(m[p], c, b1[p], b2[p], b3[p], i1[p], i2[p]);
@@ -340,7 +358,7 @@ nn_tiled_filter_kernel(NnArgs a) {
 #pragma unroll
     for (int r = 0; r < DIM; ++r) s[p][r] = -0.5f * na[p][r];      // exact
     bool third;
-    filter_decide<3>(s[p], Rt, b1[p], b2[p], b3[p], two[p], third);
+    filter_decide<DIM>(s[p], Rt, b1[p], b2[p], b3[p], two[p], third);
     fall |= (base + (int64_t)p * kNnThreads + tid < a.n) && third;
   }
 
@@ -350,8 +368,10 @@ nn_tiled_filter_kernel(NnArgs a) {
 #pragma unroll
   for (int p = 0; p < P; ++p) key[p] = kKeyInit;
   auto eval = [&](int j, unsigned long long& k, const float (&pt)[DIM]) {
-    const float4 v = tile[j];
-    const float d = dist2(pt[0], pt[1], pt[2], v.x, v.y, v.z);
+    const TP v = tile[j];
+    float d;
+    if constexpr (DIM == 2) d = dist2(pt[0], pt[1], v.x, v.y);
+    else d = dist2(pt[0], pt[1], pt[2], v.x, v.y, v.z);
     const unsigned long long cand = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
     k = cand < k ? cand : k;
   };
@@ -499,12 +519,16 @@ NnGeometry nn_geometry(int dim, int64_t n, int64_t m) {
   const int tile_max = (dim == 2) ? kNnTilePlanar : kNnTile3D;
   static const int tile_min = [] { const char* e = getenv("LSLAM_NN_TILE_MIN"); const int v = e ? atoi(e) : kNnTileMin; return v < 16 ? 16 : v; }();
   g.grid_x = (unsigned)sb;
-  // 3-D, several source points per lane (the non-fused launches): the expanded-form filter search, whose split is ONE
-  // tile of whole filter chunks — as many splits as tiles (keys: 8 bytes per source and split)
-  if (dim == 3 && g.P > 1 && nn_filter_enabled()) {
+  // Several source points per lane (the non-fused launches): the expanded-form filter search, whose split is ONE
+  // tile of whole filter chunks — as many splits as tiles (keys: 8 bytes per source and split).  Planar tiles also
+  // hold |t|² (12 bytes per point): 2048 points keep four workgroups per CU.  Planar clouds take it from 65536 source
+  // points (four per lane) only: with two points per lane the planar sweep has too few vector instructions per LDS read
+  // to gain (tools/large_planar_probe.py: 14.5 vs 16.6 ms at 100 000², 3.4 vs 3.3 ms at 40 000²).
+  if (g.P > 1 && (dim == 3 || g.P == 4) && nn_filter_enabled()) {
+    const int ftile_max = (dim == 2) ? 2048 : tile_max;
     int64_t tile = ((m + want - 1) / want + kFilterChunk - 1) / kFilterChunk * kFilterChunk;
     if (tile < tile_min) tile = (tile_min + kFilterChunk - 1) / kFilterChunk * kFilterChunk;
-    if (tile > tile_max) tile = tile_max;
+    if (tile > ftile_max) tile = ftile_max;
     const int64_t splits = (m + tile - 1) / tile;
     // one key row per split: keep the key workspace below 2 GiB (beyond that the multi-tile splits of the direct sweep)
     if (splits <= kNnMaxSplitsFilter && (double)n * (double)splits * 8.0 <= 2147483648.0) {
@@ -512,7 +536,7 @@ NnGeometry nn_geometry(int dim, int64_t n, int64_t m) {
       g.splits = (int)splits;
       g.tile_points = (int)tile;
       g.chunks_per_split = tile / CHUNK;
-      g.smem = (size_t)tile * pt_bytes;
+      g.smem = (size_t)tile * (dim == 2 ? 12 : 16);
       return g;
     }
   }
@@ -539,6 +563,8 @@ hipError_t launch_nn(NnArgs a, int dim, const NnGeometry& g, hipStream_t stream)
   const bool fuse = a.fuse_state != nullptr;                // the caller sets it only when g.P == 1
   if (dim == 2) {
     if (fuse) hipLaunchKernelGGL((nn_tiled_kernel<2, 1, true>), grid, block, g.smem, stream, a);
+    else if (g.filter && g.P == 2) hipLaunchKernelGGL((nn_tiled_filter_kernel<2, 2>), grid, block, g.smem, stream, a);
+    else if (g.filter) hipLaunchKernelGGL((nn_tiled_filter_kernel<2, 4>), grid, block, g.smem, stream, a);
     else if (g.P == 1) hipLaunchKernelGGL((nn_tiled_kernel<2, 1, false>), grid, block, g.smem, stream, a);
     else if (g.P == 2) hipLaunchKernelGGL((nn_tiled_kernel<2, 2, false>), grid, block, g.smem, stream, a);
     else hipLaunchKernelGGL((nn_tiled_kernel<2, 4, false>), grid, block, g.smem, stream, a);
@@ -546,8 +572,8 @@ hipError_t launch_nn(NnArgs a, int dim, const NnGeometry& g, hipStream_t stream)
     // the expanded-form filter sweep is the default of the 3-D search with several points per lane
     // (LSLAM_ICP_FILTER=0: direct-difference sweep); nn_geometry decides, the two kernels need different splits
     if (fuse) hipLaunchKernelGGL((nn_tiled_kernel<3, 1, true>), grid, block, g.smem, stream, a);
-    else if (g.filter && g.P == 2) hipLaunchKernelGGL((nn_tiled_filter_kernel<2>), grid, block, g.smem, stream, a);
-    else if (g.filter) hipLaunchKernelGGL((nn_tiled_filter_kernel<4>), grid, block, g.smem, stream, a);
+    else if (g.filter && g.P == 2) hipLaunchKernelGGL((nn_tiled_filter_kernel<3, 2>), grid, block, g.smem, stream, a);
+    else if (g.filter) hipLaunchKernelGGL((nn_tiled_filter_kernel<3, 4>), grid, block, g.smem, stream, a);
     else if (g.P == 1) hipLaunchKernelGGL((nn_tiled_kernel<3, 1, false>), grid, block, g.smem, stream, a);
     else if (g.P == 2) hipLaunchKernelGGL((nn_tiled_kernel<3, 2, false>), grid, block, g.smem, stream, a);
     else hipLaunchKernelGGL((nn_tiled_kernel<3, 4, false>), grid, block, g.smem, stream, a);

@@ -594,23 +594,25 @@ def test_filter_sweep_on_lattices_and_collapsed_clouds(icp, monkeypatch):
     np.testing.assert_array_equal(one.correspondences, np.argmin(d, axis=1))
 
 
+@pytest.mark.parametrize("dim", [2, 3])
 @pytest.mark.parametrize("case", ["duplicates", "lattice", "far", "tiny", "ragged_tail"])
-def test_whole_chip_filter_search_adversarial(icp, case, monkeypatch):
-    """the 3-D whole-chip search sweeps the expanded form first (nn_tiled_filter_kernel): exact duplicates in different
-    chunks and splits, lattices (every wave must re-sweep with the exact recipe), a cloud far from the origin (bound too
-    loose), sub-millimetre clouds, target counts that leave ragged chunks — all must equal the C oracle's exact recipe,
-    and the same search with the filter off"""
+def test_whole_chip_filter_search_adversarial(icp, case, dim, monkeypatch):
+    """the whole-chip search sweeps the expanded form first (nn_tiled_filter_kernel, planar and 3-D): exact duplicates in
+    different chunks and splits, lattices (every wave must re-sweep with the exact recipe), a cloud far from the origin
+    (bound too loose), sub-millimetre clouds, target counts that leave ragged chunks — all must equal the C oracle's
+    exact recipe, and the same search with the filter off"""
     from lidar_slam_amd._lib import check, lib, ptr
     from oracle import c_oracle
     monkeypatch.setenv("LSLAM_ICP_FUSE_TAIL", "0")           # three launches: the non-fused search kernels at every size
-    rng = np.random.default_rng({"duplicates": 1, "lattice": 2, "far": 3, "tiny": 4, "ragged_tail": 5}[case])
-    n, m = 9000, 20011                                      # two source points per lane: the filter search kernel
+    rng = np.random.default_rng({"duplicates": 1, "lattice": 2, "far": 3, "tiny": 4, "ragged_tail": 5}[case] + 10 * dim)
+    n, m = (9000 if dim == 3 else 66000), 20011             # the filter search kernel: from two (3-D) / four (planar) source points per lane
     if case == "lattice":
-        g = np.stack(np.meshgrid(np.arange(27), np.arange(27), np.arange(27)), -1).reshape(-1, 3) * 0.125
+        side = 27 if dim == 3 else 140
+        g = np.stack(np.meshgrid(*([np.arange(side)] * dim)), -1).reshape(-1, dim) * 0.125
         t = g[rng.permutation(g.shape[0])]
         s = g[rng.integers(0, g.shape[0], n)] + 0.0625
     else:
-        s, t = _random_problem(rng, 3, n, m if case != "ragged_tail" else 4099, spread={"tiny": 1e-3}.get(case, 2.0))
+        s, t = _random_problem(rng, dim, n, m if case != "ragged_tail" else 4099, spread={"tiny": 1e-3}.get(case, 2.0))
         if case == "duplicates":
             t[5000:5040] = t[:40]; t[19000:19040] = t[:40]
         if case == "far":
@@ -621,7 +623,7 @@ def test_whole_chip_filter_search_adversarial(icp, case, monkeypatch):
     for flt in ("1", "0"):
         monkeypatch.setenv("LSLAM_ICP_FILTER", flt)
         T = np.empty((4, 4)); err = np.empty(1); it = np.empty(1, np.int32); corr = np.empty(s32.shape[0], np.int32)
-        check(lib().lslam_icp_large(ptr(s32), s32.shape[0], ptr(t32), t32.shape[0], 3, ptr(np.eye(4)), 1e-12, 1e-4, 3, 4, ptr(T), ptr(err), ptr(it), ptr(corr), 0))
+        check(lib().lslam_icp_large(ptr(s32), s32.shape[0], ptr(t32), t32.shape[0], dim, ptr(np.eye(4)), 1e-12, 1e-4, 3, 4, ptr(T), ptr(err), ptr(it), ptr(corr), 0))
         assert it[0] == ito
         np.testing.assert_array_equal(corr, co)
         # 3000 m from the origin the float64 moments themselves lose digits to cancellation (order of summation differs)
