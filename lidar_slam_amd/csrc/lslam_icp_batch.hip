@@ -539,7 +539,9 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
   if (threads < kWave) threads = kWave;
   if (threads > kIcpBatchMaxThreads) threads = kIcpBatchMaxThreads;
   if (tune.threads > 0) threads = tune.threads;
-  bool small = threads <= kIcpSmallAutoThreads && max_tgt_n <= kIcpSmallMaxTargets;
+  // the 64-VGPR build (three workgroups per CU) pays for planar LiDAR-sized problems only: in 3-D it spills 250–500
+  // registers and the 128-VGPR filter build is 15–45 % faster at every size from 64 to 2500 points (tools/batch3d_probe.py)
+  bool small = dim == 2 && threads <= kIcpSmallAutoThreads && max_tgt_n <= kIcpSmallMaxTargets;
   if (tune.variant == 1) small = false;
   if (tune.variant == 2 && threads <= kIcpSmallMaxThreads) small = true;
   const int CHUNK = small ? ((dim == 2) ? IcpChunkSmall<2>::value : IcpChunkSmall<3>::value)
