@@ -122,8 +122,6 @@ __device__ __forceinline__ void sweep_tile(const typename TilePoint<DIM>::type* 
 
 
 // ---- the all-pairs FILTER sweep (expanded form) -------------------------------------------------
-// na[p] = −2·a[p]; per chunk of FCH targets: the minimum of g, then the update of the three smallest
-// chunk minima b1 ≤ b2 ≤ b3 and the chunk ids of the first two.
 // na[p] = −2·a[p]; per chunk of kFilterChunk targets: the minimum of g, then the update of the three smallest
 // chunk minima b1 ≤ b2 ≤ b3 and the chunk ids of the first two.  (Issuing a group's loads one group ahead of
 // its use — two register buffers held apart with scheduling barriers — was measured: no gain, 24 more VGPRs.)
