@@ -187,8 +187,34 @@ static int icp_batch_dev_impl(const float* d_src, const int64_t* d_src_off, cons
   a.init_T = d_init_T; a.out_T = d_out_T; a.out_err = d_out_err; a.out_iters = d_out_iters;
   a.out_corr = d_out_corr;
   a.epsilon = epsilon; a.stopping_thresh = stopping_thresh; a.max_iters = max_iters; a.flags = flags;
-  const bool prune = want_pruning(flags, max_src_n >= kAutoPruneBatchPoints && max_tgt_n >= kAutoPruneBatchPoints);
-  if (prune && icp_pruned_supported(dim, max_src_n, max_tgt_n)) {
+  // automatic: planar batches from kAutoPruneBatchPoints points per cloud, 3-D batches from kAutoPruneBatchPoints3D
+  const bool prune = dim == 2 ? want_pruning(flags, max_src_n >= kAutoPruneBatchPoints && max_tgt_n >= kAutoPruneBatchPoints)
+                              : want_pruning(flags, max_src_n >= kAutoPruneBatchPoints3D && max_tgt_n >= kAutoPruneBatchPoints3D);
+  if (prune && dim == 3 && icp_pruned3_supported(max_src_n, max_tgt_n)) {
+    static thread_local PruneScratch3 sc3{};
+    static thread_local size_t cap3_src = 0, cap3_tgt = 0;
+    static thread_local int sc3_dev = -1;
+    int dev = 0;
+    LSLAM_HIP_TRY(hipGetDevice(&dev));
+    const size_t need_src = (size_t)S * (size_t)max_src_n, need_tgt = (size_t)S * (size_t)max_tgt_n;   // one slot per problem
+    if (dev != sc3_dev || need_src > cap3_src || need_tgt > cap3_tgt) {
+      LSLAM_HIP_TRY(hipDeviceSynchronize());                 // earlier launches may still read the old buffers
+      if (sc3.src_sorted) (void)hipFree(sc3.src_sorted);
+      if (sc3.src_index) (void)hipFree(sc3.src_index);
+      if (sc3.tgt_sorted) (void)hipFree(sc3.tgt_sorted);
+      if (sc3.tgt_index) (void)hipFree(sc3.tgt_index);
+      sc3 = PruneScratch3{}; cap3_src = cap3_tgt = 0; sc3_dev = dev;
+      LSLAM_HIP_TRY(hipMalloc(&sc3.src_sorted, sizeof(float4) * need_src));
+      LSLAM_HIP_TRY(hipMalloc(&sc3.src_index, sizeof(uint16_t) * need_src));
+      LSLAM_HIP_TRY(hipMalloc(&sc3.tgt_sorted, sizeof(float4) * need_tgt));
+      LSLAM_HIP_TRY(hipMalloc(&sc3.tgt_index, sizeof(uint16_t) * need_tgt));
+      cap3_src = need_src; cap3_tgt = need_tgt;
+    }
+    sc3.src_stride = max_src_n; sc3.tgt_stride = max_tgt_n;
+    LSLAM_HIP_TRY(launch_icp_pruned3(a, sc3, S, max_src_n, max_tgt_n, static_cast<hipStream_t>(stream)));
+    return LSLAM_OK;
+  }
+  if (prune && dim == 2 && icp_pruned_supported(dim, max_src_n, max_tgt_n)) {
     // sorted copies in pair-local slots of S x max points (the offsets live on the device and may start anywhere)
     static thread_local PruneScratch sc{};
     static thread_local size_t cap_src = 0, cap_tgt = 0;

@@ -1,0 +1,435 @@
+// lslam_icp_pruned3d.hip — the batched ICP with EXACT box pruning for 3-D clouds (the planar kernel of
+// lslam_icp_pruned.hip carried to three dimensions; same operator, same results as icp_batch_kernel<3,·>:
+// modules/icp.py:123-189, every source gets its exact float32 nearest target, lowest original index on ties).
+//
+// icp_sort3_kernel puts both clouds of a problem into Morton order of a uniform grid over the target's box (16³ cells,
+// bitonic sort of (cell, index) keys in LDS, once per problem).  icp_pruned3_kernel then iterates on chip: per wave the
+// box of its transformed sources and its largest current bound; 64 chunk boxes (16 consecutive sorted targets each)
+// tested per ballot; the survivors re-tested with every lane's own points and current bounds, then evaluated with the
+// exact recipe; smallest and second smallest chunk minimum per source, equal minima detected from the values and
+// resolved by a rare exhaustive pass ordered by original index; float64 moments in a second phase; Jacobi-SVD solve
+// and the reference's stop rules by wave 0.  One workgroup per problem, up to 4096 targets (64 KB of LDS) and 8191
+// sources per problem.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "lslam_device.h"
+#include "lslam_kernels.h"
+
+namespace lslam {
+
+namespace {
+
+constexpr int kChunk3 = 16;
+constexpr int kSort3Threads = 256;
+constexpr float kSafety3 = 0.99999f;
+
+__device__ __forceinline__ unsigned morton4x3(unsigned x, unsigned y, unsigned z) {      // interleave three 4-bit coordinates
+  unsigned r = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) r |= ((x >> b) & 1u) << (3 * b) | ((y >> b) & 1u) << (3 * b + 1) | ((z >> b) & 1u) << (3 * b + 2);
+  return r;
+}
+__device__ __forceinline__ float wmin3(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wmax3(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float next_up3(float v) {         // the next float above a non-negative finite float (or +inf)
+  return v < INFINITY ? __uint_as_float(__float_as_uint(v) + 1u) : v;
+}
+__device__ inline void bitonic_sort3(unsigned* keys, int len) {
+  for (int k = 2; k <= len; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned a = keys[i], b = keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+    }
+  __syncthreads();
+}
+
+}  // namespace
+
+// One workgroup per problem: Morton-sorted copies of target and source (float4: x, y, z, 0) + their original indices.
+__global__ void __launch_bounds__(kSort3Threads)
+icp_sort3_kernel(IcpBatchArgs a, PruneScratch3 sc, int len_pow2) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned* keys = reinterpret_cast<unsigned*>(smem);
+  __shared__ float sbox[6];
+  __shared__ float red[kSort3Threads / 64][6];
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int64_t s0 = a.src_off[pair], t0 = a.tgt_off[pair];
+  const int n = (int)(a.src_off[pair + 1] - s0), m = (int)(a.tgt_off[pair + 1] - t0);
+  const float* src = a.src + 3 * s0;
+  const float* tgt = a.tgt + 3 * t0;
+  const int64_t ss = (int64_t)pair * sc.src_stride, ts = (int64_t)pair * sc.tgt_stride;      // pair-local scratch slots
+
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int j = tid; j < m; j += kSort3Threads)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { const float v = tgt[3 * j + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { lo[d] = wmin3(lo[d]); hi[d] = wmax3(hi[d]); }
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { red[tid >> 6][d] = lo[d]; red[tid >> 6][3 + d] = hi[d]; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < kSort3Threads / 64; ++w)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], red[w][d]); hi[d] = fmaxf(hi[d], red[w][3 + d]); }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { sbox[d] = lo[d]; sbox[3 + d] = hi[d]; }
+  }
+  __syncthreads();
+  const int G = m >= 2048 ? 16 : 8;
+  float sc3[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { lo[d] = sbox[d]; hi[d] = sbox[3 + d]; sc3[d] = (hi[d] > lo[d]) ? (float)G / (hi[d] - lo[d]) : 0.f; }
+  auto cell_of = [&](float x, float y, float z) -> unsigned {
+    int gx = (int)((x - lo[0]) * sc3[0]), gy = (int)((y - lo[1]) * sc3[1]), gz = (int)((z - lo[2]) * sc3[2]);
+    gx = min(max(gx, 0), G - 1); gy = min(max(gy, 0), G - 1); gz = min(max(gz, 0), G - 1);
+    return morton4x3((unsigned)gx, (unsigned)gy, (unsigned)gz);
+  };
+
+  // ---- target ----
+  for (int j = tid; j < len_pow2; j += kSort3Threads) {
+    unsigned k = 0xffffffffu;
+    if (j < m) k = (cell_of(tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]) << 13) | (unsigned)j;
+    keys[j] = k;
+  }
+  bitonic_sort3(keys, len_pow2);
+  for (int j = tid; j < m; j += kSort3Threads) {
+    const unsigned o = keys[j] & 8191u;
+    sc.tgt_sorted[ts + j] = make_float4(tgt[3 * o], tgt[3 * o + 1], tgt[3 * o + 2], 0.f);
+    sc.tgt_index[ts + j] = (uint16_t)o;
+  }
+  __syncthreads();
+  // ---- source, placed by its initial transform into the target's grid ----
+  const double* T = a.init_T + (int64_t)16 * pair;
+  float t[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t[r][c] = (float)T[4 * r + c];
+  for (int i = tid; i < len_pow2; i += kSort3Threads) {
+    unsigned k = 0xffffffffu;
+    if (i < n) {
+      const float x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
+      k = (cell_of(t[0][0] * x + t[0][1] * y + t[0][2] * z + t[0][3], t[1][0] * x + t[1][1] * y + t[1][2] * z + t[1][3],
+                   t[2][0] * x + t[2][1] * y + t[2][2] * z + t[2][3]) << 13) | (unsigned)i;
+    }
+    keys[i] = k;
+  }
+  bitonic_sort3(keys, len_pow2);
+  for (int i = tid; i < n; i += kSort3Threads) {
+    const unsigned o = keys[i] & 8191u;
+    sc.src_sorted[ss + i] = make_float4(src[3 * o], src[3 * o + 1], src[3 * o + 2], 0.f);
+    sc.src_index[ss + i] = (uint16_t)o;
+  }
+}
+
+template <int P>
+__global__ void __launch_bounds__(kIcpBatchMaxThreads)
+icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
+  constexpr int CHUNK = kChunk3;
+  constexpr int kAcc = AccLayout<3>::kTotal;
+  extern __shared__ __align__(16) unsigned char smem[];
+  float4* tile = reinterpret_cast<float4*>(smem);                                   // sorted targets, padded
+  float4* aabb = reinterpret_cast<float4*>(smem + lay.aabb_off);                    // per chunk: lo (x, y, z), hi (x, y, z)
+  float4* sh_src = reinterpret_cast<float4*>(smem + lay.src_off);                   // sorted sources (when they fit)
+  uint16_t* sh_prev = reinterpret_cast<uint16_t*>(smem + lay.prev_off);             // last match (sorted target position) of every source
+  double* sh_red = reinterpret_cast<double*>(smem + lay.red_off);                   // [waves][kAcc]
+  double* sh_T = sh_red + (size_t)kIcpBatchMaxWaves * kAcc;
+  double* sh_err = sh_T + 16;
+  StopState* sh_stop = reinterpret_cast<StopState*>(sh_err + 1);
+  int* sh_flag = reinterpret_cast<int*>(sh_stop + 1);
+
+  const int pair = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int64_t s0 = args.src_off[pair], t0 = args.tgt_off[pair];
+  const int n = (int)(args.src_off[pair + 1] - s0), m = (int)(args.tgt_off[pair + 1] - t0);
+  const int64_t ss = (int64_t)pair * sc.src_stride, ts = (int64_t)pair * sc.tgt_stride;
+  const float4* __restrict__ ssrc = sc.src_sorted + ss;
+  const uint16_t* __restrict__ tidx = sc.tgt_index + ts;       // original target index: ties and final correspondences only
+  const bool box = (args.flags & kFlagNormalize) != 0;
+  const int nchunks = (m + CHUNK - 1) / CHUNK;
+
+  if (tid < 16) sh_T[tid] = args.init_T[(int64_t)16 * pair + tid];
+  for (int j = tid; j < nchunks * CHUNK; j += blockDim.x) tile[j] = (j < m) ? sc.tgt_sorted[ts + j] : make_float4(kFar, kFar, kFar, 0.f);
+  const bool src_lds = lay.src_off != 0xffffffffu;
+  for (int i = tid; i < n; i += blockDim.x) { if (src_lds) sh_src[i] = ssrc[i]; sh_prev[i] = 0xffff; }
+  __syncthreads();
+  for (int c = tid; c < nchunks; c += blockDim.x) {          // boxes over the real points only
+    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+    for (int k = 0; k < CHUNK && c * CHUNK + k < m; ++k) {
+      const float4 q = tile[c * CHUNK + k];
+      lo.x = fminf(lo.x, q.x); lo.y = fminf(lo.y, q.y); lo.z = fminf(lo.z, q.z);
+      hi.x = fmaxf(hi.x, q.x); hi.y = fmaxf(hi.y, q.y); hi.z = fmaxf(hi.z, q.z);
+    }
+    aabb[2 * c] = lo; aabb[2 * c + 1] = hi;
+  }
+  if (tid == 0) { StopState st0; stop_init(st0); *sh_stop = st0; *sh_err = 0.0; }
+  __syncthreads();
+  const int per_pass = blockDim.x * P;
+  const int passes = n > 0 ? (n + per_pass - 1) / per_pass : 1;
+
+  // lower bound of the distance² from the box [lo, hi] to the box [blo, bhi] (a point when lo == hi)
+  auto box_dist = [](const float (&lo)[3], const float (&hi)[3], const float4 blo, const float4 bhi) -> float {
+    const float dx = fmaxf(fmaxf(blo.x - hi[0], lo[0] - bhi.x), 0.f);
+    const float dy = fmaxf(fmaxf(blo.y - hi[1], lo[1] - bhi.y), 0.f);
+    const float dz = fmaxf(fmaxf(blo.z - hi[2], lo[2] - bhi.z), 0.f);
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * kSafety3;
+  };
+
+  for (;;) {
+    double T[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) T[r][c] = wave_uniform(sh_T[4 * r + c]);
+
+    // ---- phase A: nearest neighbours (float32); the matches go to LDS (they also seed the next iteration)
+    for (int pass = 0; pass < passes; ++pass) {
+      const int base = pass * per_pass;
+      if (base + (tid & ~63) * P >= n) continue;             // this wave owns no source in this pass
+      float a[P][3];
+      float wlo[3] = {INFINITY, INFINITY, INFINITY}, whi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = base + tid * P + p;
+        a[p][0] = a[p][1] = a[p][2] = 0.f;
+        if (i < n) {
+          const float4 v = src_lds ? sh_src[i] : ssrc[i];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {                      // icp.py:116
+            a[p][r] = (float)(T[r][0] * (double)v.x + T[r][1] * (double)v.y + T[r][2] * (double)v.z + T[r][3]);
+            wlo[r] = fminf(wlo[r], a[p][r]); whi[r] = fmaxf(whi[r], a[p][r]);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { wlo[r] = wmin3(wlo[r]); whi[r] = wmax3(whi[r]); }
+
+      // ---- start from last iteration's match (first iteration: the target at the same rank along the curve) ----
+      float best[P], second[P];                              // smallest and second smallest chunk minimum seen so far
+      int bchunk[P];
+      bool tie = false;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = base + tid * P + p;
+        best[p] = (i < n) ? INFINITY : -INFINITY;            // lanes without a point never ask for a chunk
+        second[p] = INFINITY;
+        bchunk[p] = 0;
+        if (i < n) {
+          int pv = sh_prev[i];
+          if (pv == 0xffff) pv = (int)(((long long)i * m) / n);
+          const float4 q = tile[pv];
+          best[p] = next_up3(dist2(a[p][0], a[p][1], a[p][2], q.x, q.y, q.z));   // a bound, not yet a candidate: its chunk will beat it strictly
+          bchunk[p] = pv / CHUNK;
+        }
+      }
+
+      // ---- sweep: 64 chunk boxes per ballot against the wave's box and largest bound; survivors get a second look with
+      // every lane's own points and current bounds, then are evaluated with the exact recipe
+      float wb = -INFINITY;
+#pragma unroll
+      for (int p = 0; p < P; ++p) wb = fmaxf(wb, best[p]);
+      wb = wmax3(wb);
+      for (int c0 = 0; c0 < nchunks; c0 += 64) {
+        bool cand = false;
+        if (c0 + lane < nchunks) cand = wb >= box_dist(wlo, whi, aabb[2 * (c0 + lane)], aabb[2 * (c0 + lane) + 1]);
+        unsigned long long todo = __ballot(cand);
+        while (todo) {
+          const int c = c0 + __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const float4 blo = aabb[2 * c], bhi = aabb[2 * c + 1];
+          bool need_own = false;
+#pragma unroll
+          for (int p = 0; p < P; ++p) need_own |= best[p] >= box_dist(a[p], a[p], blo, bhi);
+          if (!__any(need_own)) continue;                    // nothing in this chunk can beat or tie any lane
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            float mn = INFINITY;
+#pragma unroll
+            for (int k = 0; k < CHUNK; k += 2) {
+              const float4 q0 = tile[c * CHUNK + k], q1 = tile[c * CHUNK + k + 1];
+              mn = fminf(fminf(dist2(a[p][0], a[p][1], a[p][2], q0.x, q0.y, q0.z), dist2(a[p][0], a[p][1], a[p][2], q1.x, q1.y, q1.z)), mn);
+            }
+            const bool lt = mn < best[p];
+            second[p] = __builtin_amdgcn_fmed3f(best[p], second[p], mn);
+            bchunk[p] = lt ? c : bchunk[p];
+            best[p] = lt ? mn : best[p];
+          }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) tie |= (second[p] == best[p]) && (best[p] < INFINITY);
+
+      // ---- fix-up inside the winning chunk: position of the minimum; equal distances are left to the pass below ----
+      int pos[P];
+      float bd[P];
+      int rot = lane;
+      asm volatile("" : "+v"(rot));                          // opaque: keeps the 16 rotated offsets from being hoisted out of the ICP loop
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int j0 = bchunk[p] * CHUNK;
+        float sec2 = INFINITY;
+        bd[p] = INFINITY; pos[p] = j0;
+#pragma unroll
+        for (int kk = 0; kk < CHUNK; ++kk) {
+          const int k = (kk + rot) & (CHUNK - 1);
+          const float4 q = tile[j0 + k];
+          const float d = dist2(a[p][0], a[p][1], a[p][2], q.x, q.y, q.z);
+          const bool lt = d < bd[p];
+          sec2 = __builtin_amdgcn_fmed3f(bd[p], sec2, d);
+          pos[p] = lt ? j0 + k : pos[p];
+          bd[p] = lt ? d : bd[p];
+        }
+        tie |= (sec2 == bd[p]) && (bd[p] < INFINITY);
+      }
+      // ---- equal minima (duplicate or equidistant points): exhaustive pass, lowest ORIGINAL index wins --
+      if (__any(tie)) {
+        int oidx[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) { bd[p] = INFINITY; oidx[p] = 0x7fffffff; }
+        for (int j = 0; j < m; ++j) {
+          const float4 q = tile[j];
+          const int o = tidx[j];
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            const float d = dist2(a[p][0], a[p][1], a[p][2], q.x, q.y, q.z);
+            if (d < bd[p] || (d == bd[p] && o < oidx[p])) { bd[p] = d; pos[p] = j; oidx[p] = o; }
+          }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = base + tid * P + p;
+        if (i < n) sh_prev[i] = (uint16_t)pos[p];
+      }
+    }
+
+    // ---- phase B: float64 moments of the matched pairs ----------------------------------------------------------
+    PairAcc<3> acc;
+    acc.clear();
+    for (int pass = 0; pass < passes; ++pass) {
+      const int base = pass * per_pass;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = base + tid * P + p;
+        if (i < n) {
+          const float4 v = src_lds ? sh_src[i] : ssrc[i];
+          const float4 q = tile[sh_prev[i]];
+          double pd[3], qd[3];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) pd[r] = T[r][0] * (double)v.x + T[r][1] * (double)v.y + T[r][2] * (double)v.z + T[r][3];
+          qd[0] = (double)q.x; qd[1] = (double)q.y; qd[2] = (double)q.z;
+          acc.add(pd, qd, box);
+        }
+      }
+    }
+    acc.wave_reduce(box);
+    if (lane == 0) acc.store(sh_red + (size_t)wave * kAcc);
+    __syncthreads();
+    if (wave == 0) {
+      constexpr int kS = AccLayout<3>::kSums;
+      double col = 0.0;
+      if (lane < kAcc) {
+        col = sh_red[lane];
+        for (int w = 1; w < nwaves; ++w) {
+          const double v = sh_red[(size_t)w * kAcc + lane];
+          col = (lane < kS) ? col + v : ((lane < kS + 3) ? fmin(col, v) : fmax(col, v));
+        }
+      }
+      double tot[kAcc];
+#pragma unroll
+      for (int k = 0; k < kAcc; ++k) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(col), k);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(col), k);
+        tot[k] = __hiloint2double(hi, lo);
+      }
+      Moments mo;
+      combine_partials<3>(tot, 1, kAcc, box, mo);
+      double Tstep[16], Tprev[16], Tnew[16];
+      step_from_moments(mo, false, Tstep);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Tprev[i] = sh_T[i];
+      matmul4(Tstep, Tprev, Tnew);
+      const double err = error_from_moments(mo, box);
+      StopState st = *sh_stop;
+      const bool stop = stop_after_iteration(st, err, args.epsilon, args.stopping_thresh, args.max_iters);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sh_T[i] = Tnew[i];
+        sh_flag[0] = stop ? 1 : 0;
+        *sh_stop = st;
+        *sh_err = err;
+      }
+    }
+    __syncthreads();
+    if (sh_flag[0]) break;
+  }
+
+  if (tid < 16) args.out_T[(int64_t)16 * pair + tid] = sh_T[tid];
+  if (tid == 0) {
+    args.out_err[pair] = *sh_err;
+    args.out_iters[pair] = sh_stop->executed;
+  }
+  // correspondences of the LAST iteration (icp.py:117, 187-189), in the caller's numbering
+  if (args.out_corr)
+    for (int i = tid; i < n; i += blockDim.x) args.out_corr[s0 + sc.src_index[ss + i]] = tidx[sh_prev[i]];
+}
+
+// ---- launch ------------------------------------------------------------------------------------------
+bool icp_pruned3_supported(int64_t max_src_n, int64_t max_tgt_n) {
+  return max_src_n >= 1 && max_src_n <= kPrune3MaxSrc && max_tgt_n >= 1 && max_tgt_n <= kPrune3MaxTgt;
+}
+
+hipError_t launch_icp_pruned3(IcpBatchArgs a, const PruneScratch3& sc, int S, int64_t max_src_n, int64_t max_tgt_n, hipStream_t stream) {
+  int len = 64;
+  while (len < max_src_n || len < max_tgt_n) len <<= 1;
+  hipLaunchKernelGGL(icp_sort3_kernel, dim3(S), dim3(kSort3Threads), sizeof(unsigned) * (size_t)len, stream, a, sc, len);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  int P = 1;
+  if (const char* env = getenv("LSLAM_ICP_PRUNE_P")) { const int v = atoi(env); if (v == 1 || v == 2) P = v; }
+  int threads = (int)((((max_src_n + P - 1) / P + 63) / 64) * 64);
+  if (threads < 64) threads = 64;
+  if (threads > kIcpBatchMaxThreads) threads = kIcpBatchMaxThreads;      // more sources: several passes
+  const int padded = (int)(((max_tgt_n + kChunk3 - 1) / kChunk3) * kChunk3);
+  const int nchunks = padded / kChunk3;
+  PruneLayout lay{};
+  auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  size_t off = (size_t)padded * sizeof(float4);
+  lay.aabb_off = (uint32_t)off; off += (size_t)nchunks * 2 * sizeof(float4);
+  const size_t tail = up((size_t)max_src_n * sizeof(uint16_t)) + sizeof(double) * ((size_t)kIcpBatchMaxWaves * AccLayout<3>::kTotal + 17) + sizeof(StopState) + 16;
+  if (off + up((size_t)max_src_n * sizeof(float4)) + tail > 156 * 1024) lay.src_off = 0xffffffffu;     // sources stay in global memory (L2)
+  else { lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(float4)); }
+  lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));
+  lay.red_off = (uint32_t)off;
+  const size_t smem = off + sizeof(double) * ((size_t)kIcpBatchMaxWaves * AccLayout<3>::kTotal + 17) + sizeof(StopState) + 16;
+  auto launch = [&](auto kernel) -> hipError_t {
+    if (smem > 48 * 1024) {
+      hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (ee != hipSuccess) return ee;
+    }
+    hipLaunchKernelGGL(kernel, dim3(S), dim3(threads), smem, stream, a, sc, lay);
+    return hipGetLastError();
+  };
+  if (P == 2) return launch(icp_pruned3_kernel<2>);
+  return launch(icp_pruned3_kernel<1>);
+}
+
+}  // namespace lslam

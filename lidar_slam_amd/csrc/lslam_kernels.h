@@ -72,6 +72,18 @@ bool icp_pruned_supported(int dim, int64_t max_src_n, int64_t max_tgt_n);
 hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n,
                              hipStream_t stream);
 
+// 3-D problems (lslam_icp_pruned3d.hip): float4 sorted copies, up to 4096 targets (one 64 KB LDS tile) and 8191 sources
+constexpr int kPrune3MaxTgt = 4096;
+constexpr int kPrune3MaxSrc = 8191;
+constexpr int64_t kAutoPruneBatchPoints3D = 2000;        // automatic choice for 3-D batches (tools/batch3d_probe.py: 1.75 vs 2.39 ms at 2000 points, 1.72 vs 1.43 at 1000)
+struct PruneScratch3 {
+  float4* src_sorted; uint16_t* src_index;
+  float4* tgt_sorted; uint16_t* tgt_index;
+  int64_t src_stride, tgt_stride;
+};
+bool icp_pruned3_supported(int64_t max_src_n, int64_t max_tgt_n);
+hipError_t launch_icp_pruned3(IcpBatchArgs a, const PruneScratch3& sc, int S, int64_t max_src_n, int64_t max_tgt_n, hipStream_t stream);
+
 hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, int64_t max_tgt_n,
                             const IcpBatchTuning& tune, hipStream_t stream);
 

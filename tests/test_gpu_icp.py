@@ -734,3 +734,45 @@ def test_full_size_dense_3d_identity_search(icp, strategy, monkeypatch):
     assert it == 1 and err == 0.0
     np.testing.assert_array_equal(corr.cpu().numpy(), np.arange(tgt.shape[0], dtype=np.int32))
     np.testing.assert_allclose(T, np.eye(4), atol=1e-12)
+
+
+def test_exact_pruning_3d_gives_the_brute_force_answers(icp):
+    """the 3-D pruned batch kernel (Morton-sorted float4 copies, 16³ grid, chunk boxes in 3-D): identical correspondences and
+    iteration counts as the all-pairs sweep and as the C oracle's exact recipe — ragged sizes up to the kernel's limits
+    (4096 targets, 8191 sources), duplicates far apart in index, a lattice with massive ties, a collapsed target,
+    normalised error, a sub-range of a packed buffer"""
+    from lidar_slam_amd.batch import icp_batch, pack_clouds
+    from oracle import c_oracle
+    rng = np.random.default_rng(333)
+    sizes = [(8, 6), (100, 3000), (4096, 4096), (3000, 700), (8191, 64), (513, 4096), (6000, 4000), (1500, 1500)]
+    ss, ts = [], []
+    for n, m in sizes:
+        s_, t_ = _random_problem(rng, 3, n, m, spread=rng.uniform(0.05, 20.0))
+        if m > 40:
+            t_[m // 2] = t_[3]; t_[m - 1] = t_[3]          # exact duplicates far apart in index
+        ss.append(s_); ts.append(t_)
+    g = np.stack(np.meshgrid(np.arange(14), np.arange(14), np.arange(14)), -1).reshape(-1, 3) * 0.25
+    ss.append(g[rng.integers(0, g.shape[0], 2000)] + 0.125); ts.append(g[rng.permutation(g.shape[0])])     # 8-way ties everywhere
+    # (a target collapsed to ONE point is left out in 3-D: its cross-covariance is rounding noise and the rotation, hence the
+    #  iteration count, follows the summation order — parity undefined in the reference too, SURVEY I5)
+    fs, so = pack_clouds(ss)
+    ft, to = pack_clouds(ts)
+    I = np.tile(np.eye(4), (len(ss), 1, 1))
+    for norm in (False, True):
+        kw = dict(epsilon=1e-12, max_iters=8, normalize_error=norm, return_correspondences=True)
+        a = icp_batch(fs, so, ft, to, I, prune=False, **kw)
+        b = icp_batch(fs, so, ft, to, I, prune=True, **kw)
+        np.testing.assert_array_equal(b.iterations, a.iterations)
+        np.testing.assert_array_equal(b.correspondences, a.correspondences)
+        ok = np.isfinite(a.T).all(axis=(1, 2))
+        ok[0] = False                                         # 8 sources on 6 targets may match two of them only: rotation not unique (SURVEY I5)
+        np.testing.assert_allclose(b.T[ok], a.T[ok], atol=1e-9)
+    c = icp_batch(fs, so, ft, to, I, prune=True, epsilon=1e-12, max_iters=8, return_correspondences=True)
+    for k in (2, 5, 6):
+        To, eo, co, ito = c_oracle.run_icp(ss[k], ts[k], np.eye(4), epsilon=1e-12, max_iters=8, recipe="device")
+        assert c.iterations[k] == ito
+        np.testing.assert_array_equal(c.correspondences[so[k]:so[k + 1]], co)
+        np.testing.assert_allclose(c.T[k], To, atol=1e-9)
+    sub = icp_batch(fs, so[5:8], ft, to[5:8], I[5:7], prune=True, epsilon=1e-12, max_iters=8, return_correspondences=True)
+    np.testing.assert_array_equal(sub.correspondences[so[5]:so[7]], c.correspondences[so[5]:so[7]])
+    np.testing.assert_allclose(sub.T, c.T[5:7], atol=1e-10)
