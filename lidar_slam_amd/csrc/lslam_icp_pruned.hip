@@ -450,8 +450,7 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
   size_t off = (size_t)padded * sizeof(float2);
   lay.aabb_off = (uint32_t)off; off += (size_t)nchunks * sizeof(float4);
-  if (getenv("LSLAM_PRUNE_SRC_GLOBAL")) lay.src_off = 0xffffffffu;
-  else { lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(float2)); }
+  lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(float2));
   lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));
   lay.red_off = (uint32_t)off;
   const size_t smem = off + sizeof(double) * ((size_t)kIcpBatchMaxWaves * AccLayout<2>::kTotal + 16 + 1) + sizeof(StopState) + 16;
