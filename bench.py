@@ -138,9 +138,85 @@ def cpu_baseline_all_cores(src, tgt, init, P, n_pairs, iters):
     return total / (time.perf_counter() - t0), cores
 
 
+# -------------------------------------------------------------------------------------- launcher
+def launch_plan(gpus, env):
+    """What `python bench.py --gpus N` has to do, decided from the flags and the environment alone (no GPU call):
+    "single" — one process, one GPU; "rank" — this process IS one rank of a job somebody else started
+    (torch.distributed.run / the driver: RANK, WORLD_SIZE in the environment); "spawn" — N > 1 was asked for and
+    nobody started the ranks, so this process starts them itself (and never touches a GPU)."""
+    if "WORLD_SIZE" in env and "RANK" in env:
+        world = int(env["WORLD_SIZE"])
+        if gpus not in (1, world):
+            raise SystemExit(f"bench.py: --gpus {gpus} contradicts WORLD_SIZE={world} of the launcher")
+        return "rank" if world > 1 else "single"
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    return "spawn" if gpus > 1 else "single"
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(gpus, argv, env=None):
+    """Start `gpus` fresh rank processes of this script (one per LOCAL_RANK, the environment torch.distributed.run would
+    give them), relay rank 0's single JSON line, and fail if any rank fails.  The parent makes no HIP call — the children
+    are new processes (never a re-exec of a process that has touched the GPU).  Returns the exit code."""
+    import subprocess
+    base = dict(os.environ if env is None else env)
+    base.update({"WORLD_SIZE": str(gpus), "LOCAL_WORLD_SIZE": str(gpus), "MASTER_ADDR": "127.0.0.1",
+                 "MASTER_PORT": base.get("MASTER_PORT") or str(_free_port()), "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    procs = []
+    for r in range(gpus):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    code = 0
+    pending = set(range(gpus))
+    out0 = b""
+    try:
+        while pending:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if r == 0:
+                    out0 = procs[0].stdout.read()
+                if rc != 0:
+                    code = code or rc
+                    print(f"bench.py: rank {r} exited with {rc}", file=sys.stderr)
+            if code:
+                break
+            if pending:
+                time.sleep(0.05)
+    finally:
+        for r in pending:                                          # a rank failed: the others would wait in the rendezvous forever
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    if code == 0:
+        lines = [l for l in out0.decode().splitlines() if l.strip()]
+        if len(lines) != 1:
+            print(f"bench.py: rank 0 printed {len(lines)} lines, expected one JSON line", file=sys.stderr)
+            return 1
+        sys.stdout.write(lines[0] + "\n")
+        sys.stdout.flush()
+    return code
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
+    plan = launch_plan(a.gpus, os.environ)
+    if plan == "spawn":
+        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))
     # Libraries talk on stdout (RCCL prints a version banner when its first communicator comes up): everything but
     # the one JSON line goes to stderr, whoever writes it.
     sys.stdout.flush()
@@ -149,13 +225,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        a.gpus = world
+    a.gpus = world
     import torch
     import torch.distributed as dist
 
-    if torch.cuda.device_count() < 1:                           # counting devices does not initialise HIP
+    ndev = torch.cuda.device_count()                            # amdsmi-backed on this image: no HIP context yet
+    if ndev < 1:
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    if local_rank >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but this node shows {ndev} GPU(s); --gpus {world} cannot run here")
     # The CPU-baseline legs run BEFORE anything initialises HIP in this process: the all-cores leg forks a
     # process pool, and a forked child of a GPU-initialised process inherits runtime threads and KFD mappings.
     cpu_baseline = None
@@ -179,6 +257,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        assert dist.get_world_size() == world, (dist.get_world_size(), world)      # n_gpus below = the ranks RCCL reports
 
     from lidar_slam_amd import batch as B
     from lidar_slam_amd._lib import check, lib
@@ -238,7 +317,7 @@ def main():
         prof = profile_figures("c4", HEADLINE_KERNEL)
         result = {
             "metric": "icp_iterations_per_sec", "value": total_iters / dt, "unit": "iterations/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "n_gpus": dist.get_world_size() if use_dist else 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C4 synthetic batch: {S} scan pairs per GPU x {P}x{P} planar points, {I} forced ICP iterations per pair",
                        "pairs_per_gpu": S, "points": P, "iterations": I, "sharding": f"independent pairs over {world} GPU(s), all-gather of poses", "search": "all pairs (LSLAM_ICP_ALL_PAIRS)"},

@@ -38,3 +38,49 @@ def test_refuses_to_run_without_a_gpu():
                        env={**os.environ, "HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""}, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == ""          # no JSON line, no CPU fallback
     assert "GPU" in r.stderr
+
+
+def test_launch_plan_decides_who_starts_the_ranks():
+    """`--gpus N` without a launcher's environment must start N ranks itself (it used to run ONE rank silently);
+    under torch.distributed.run the process is a rank; a contradiction between the two is an error."""
+    import pytest
+    import bench
+    assert bench.launch_plan(1, {}) == "single"
+    assert bench.launch_plan(8, {}) == "spawn"
+    assert bench.launch_plan(2, {"PATH": "/bin"}) == "spawn"
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3"}) == "rank"
+    assert bench.launch_plan(1, {"WORLD_SIZE": "4", "RANK": "0"}) == "rank"          # flag left at its default under a launcher
+    assert bench.launch_plan(1, {"WORLD_SIZE": "1", "RANK": "0"}) == "single"
+    with pytest.raises(SystemExit):
+        bench.launch_plan(4, {"WORLD_SIZE": "8", "RANK": "0"})
+    with pytest.raises(SystemExit):
+        bench.launch_plan(0, {})
+
+
+def test_gpus_2_without_two_gpus_fails_loudly_instead_of_measuring_one():
+    """no GPU here: every spawned rank must refuse, the parent must relay the failure and print no JSON line"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, env={**os.environ, "HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""}, timeout=600)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "rank" in r.stderr and "GPU" in r.stderr
+
+
+def test_spawned_ranks_get_a_launcher_environment_and_rank0_line_is_relayed(tmp_path):
+    """spawn_ranks() with a stand-in rank program: N fresh processes, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set,
+    rank 0's one line relayed on stdout, a failing rank makes the whole call fail"""
+    prog = tmp_path / "fake_rank.py"
+    prog.write_text("import os, sys, json\n"
+                    "r = int(os.environ['RANK']); assert os.environ['LOCAL_RANK'] == str(r)\n"
+                    "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                    "open(os.path.join(os.path.dirname(__file__), f'seen{r}'), 'w').write(os.environ['WORLD_SIZE'])\n"
+                    "if r == 0: print(json.dumps({'n_gpus': int(os.environ['WORLD_SIZE'])}))\n"
+                    "sys.exit(int(os.environ.get('FAIL_RANK', '-1')) == r)\n")
+    code = subprocess.run([sys.executable, "-c",
+                           f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.__file__ = {str(prog)!r}; "
+                           "sys.exit(bench.spawn_ranks(3, []))"], capture_output=True, text=True, timeout=120)
+    assert code.returncode == 0 and code.stdout.strip() == '{"n_gpus": 3}'
+    assert sorted(f.name for f in tmp_path.glob("seen*")) == ["seen0", "seen1", "seen2"]
+    bad = subprocess.run([sys.executable, "-c",
+                          f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.__file__ = {str(prog)!r}; "
+                          "sys.exit(bench.spawn_ranks(3, []))"], capture_output=True, text=True, timeout=120, env={**os.environ, "FAIL_RANK": "2"})
+    assert bad.returncode != 0 and bad.stdout.strip() == "" and "rank 2" in bad.stderr
