@@ -113,6 +113,35 @@ int lslam_icp_batch_dev(const float *d_src, const int64_t *d_src_off,
                         double *d_out_T, double *d_out_err, int32_t *d_out_iters,
                         int32_t *d_out_corr, void *stream);
 
+/* ---- float64-exact mode ---------------------------------------------------
+ * The reference searches its nearest neighbours in float64 (scipy KDTree on float64 points,
+ * modules/icp.py:29-41,161).  The entry points above take float32 points: their correspondences are those
+ * of an exact float32 search, which differs from the reference's wherever rounding the points to float32
+ * flips a near tie.  The entry points below take the float64 clouds as well.  The float32 search then only
+ * proposes candidates: every target whose float32 distance lies within a proven bound of the winner's
+ *  is re-evaluated as |T p - q|^2 in float64 on the float64 points, lowest index on exact
+ * float64 ties, and the moments / error are accumulated from the float64 points.  Correspondences are then
+ * those of modules/icp.py:29-41 (up to ties the KD-tree breaks arbitrarily) and T, error agree with the
+ * reference to float64 summation order.  Same arguments otherwise; same search strategies.
+ * lslam_icp_batch_f64: host float64 clouds (uploaded once, rounded to float32 on the device).
+ * lslam_icp_batch_dev64: device pointers to BOTH copies, laid out alike (d_src64 / d_tgt64 may both be NULL:
+ * then it is lslam_icp_batch_dev). */
+int lslam_icp_batch_f64(const double *src, const int64_t *src_off,
+                        const double *tgt, const int64_t *tgt_off,
+                        int dim, const double *init_T, int32_t S,
+                        double epsilon, double stopping_thresh, int32_t max_iters,
+                        uint32_t flags,
+                        double *out_T, double *out_err, int32_t *out_iters,
+                        int32_t *out_corr, int device);
+int lslam_icp_batch_dev64(const float *d_src, const double *d_src64, const int64_t *d_src_off,
+                          const float *d_tgt, const double *d_tgt64, const int64_t *d_tgt_off,
+                          int dim, const double *d_init_T, int32_t S,
+                          int64_t max_src_n, int64_t max_tgt_n,
+                          double epsilon, double stopping_thresh, int32_t max_iters,
+                          uint32_t flags,
+                          double *d_out_T, double *d_out_err, int32_t *d_out_iters,
+                          int32_t *d_out_corr, void *stream);
+
 /* ---- ICP on ONE large cloud pair (whole chip on one problem) ------------ */
 /*
  * run_icp for clouds too large for one workgroup (config "100k x 100k"): per

@@ -57,21 +57,23 @@ for _name in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "e
     setattr(PackedScans, _name, _invalidating(_name))
 
 
-def pack_clouds(clouds):
-    """list of (n_i, d) arrays -> (float32 (Σn_i, d) C-contiguous, int64 offsets (len+1,))"""
+def pack_clouds(clouds, dtype=np.float64):
+    """list of (n_i, d) arrays -> (``dtype`` (Σn_i, d) C-contiguous, int64 offsets (len+1,)).
+    float64 (the default) keeps the points as the reference has them — ``icp_batch`` then runs in float64-exact mode;
+    float32 rounds them in the same pass (half the upload, float32-exact search)."""
     if isinstance(clouds, PackedScans):
         packed = clouds.packed()
         if packed is not None:
-            return np.ascontiguousarray(packed[0], dtype=np.float32), packed[1]
+            return np.ascontiguousarray(packed[0], dtype=dtype), packed[1]
     d = clouds[0].shape[1] if len(clouds) else 2
     off = np.zeros(len(clouds) + 1, dtype=np.int64)
     off[1:] = np.cumsum([c.shape[0] for c in clouds])
     if any(c.ndim != 2 or c.shape[1] != d for c in clouds):
         raise ValueError("all clouds of a batch must be (n_i, d) with the same d")
     if not len(clouds):
-        return np.zeros((0, d), np.float32), off
-    flat = np.empty((int(off[-1]), d), dtype=np.float32)
-    np.concatenate(clouds, axis=0, out=flat, casting="same_kind")      # one pass: gather and round to float32
+        return np.zeros((0, d), dtype), off
+    flat = np.empty((int(off[-1]), d), dtype=dtype)
+    np.concatenate(clouds, axis=0, out=flat, casting="same_kind")      # one pass: gather (and round, for float32)
     return flat, off
 
 
@@ -79,13 +81,21 @@ def icp_batch(src, src_off, tgt, tgt_off, init_T, epsilon=0.01, max_iters=2000, 
               normalize_error=False, return_correspondences=False, device=0, prune=None) -> IcpBatchResult:
     """S independent run_icp problems (modules/icp.py:123-189) in one launch, host arrays in/out.
 
-    src, tgt: float32 (N,d) packed clouds (d = 2 or 3; they may be the same array for a scan
-    sequence); src_off, tgt_off: int64 (S+1,) point offsets; init_T: (S,4,4) float64.
+    src, tgt: (N,d) packed clouds (d = 2 or 3; they may be the same array for a scan sequence), both float64 or
+    both float32; src_off, tgt_off: int64 (S+1,) point offsets; init_T: (S,4,4) float64.
+    float64 clouds run in FLOAT64-EXACT mode (``lslam_icp_batch_f64``): the float32 search only proposes candidates,
+    near ties are decided and the moments accumulated on the float64 points — correspondences are those of the
+    reference's float64 search (modules/icp.py:29-41), T / error agree with it to summation order.  float32 clouds
+    (``lslam_icp_batch``) are searched as they are: exact float32 nearest neighbours.
     ``prune``: None = the library picks the search strategy, True = exact spatial pruning (planar problems of
-    ≤ 4096 points per cloud: both clouds sorted spatially, target chunks that provably cannot hold a nearer
-    point skipped), False = the all-pairs sweep.  Same correspondences and iteration counts either way."""
-    src = np.ascontiguousarray(src, dtype=np.float32)
-    tgt = src if tgt is src else np.ascontiguousarray(tgt, dtype=np.float32)
+    ≤ 4096 points per cloud, 3-D of ≤ 4096 target / 8191 source points: both clouds sorted spatially, target chunks
+    that provably cannot hold a nearer point skipped), False = the all-pairs sweep.  Same correspondences and
+    iteration counts either way."""
+    same = tgt is src
+    src = np.asarray(src)
+    dtype = np.float32 if (src.dtype == np.float32 and np.asarray(tgt).dtype == np.float32) else np.float64
+    src = np.ascontiguousarray(src, dtype=dtype)
+    tgt = src if same else np.ascontiguousarray(tgt, dtype=dtype)
     if src.ndim != 2 or src.shape[1] not in (2, 3) or tgt.ndim != 2 or tgt.shape[1] != src.shape[1]:
         raise ValueError("clouds must be (N,2) or (N,3) with equal dimension")
     src_off = np.ascontiguousarray(src_off, dtype=np.int64)
@@ -101,21 +111,23 @@ def icp_batch(src, src_off, tgt, tgt_off, init_T, epsilon=0.01, max_iters=2000, 
     out_it = np.empty(S, dtype=np.int32)
     corr = np.empty(int(src_off[-1]) if S else 0, dtype=np.int32) if return_correspondences else None
     flags = (_lib.ICP_NORMALIZE_ERROR if normalize_error else 0) | _lib.search_flags(prune)
-    check(lib().lslam_icp_batch(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), src.shape[1], ptr(init_T), S,
-                                float(epsilon), float(stopping_thresh), int(max_iters), flags,
-                                ptr(out_T), ptr(out_err), ptr(out_it), ptr(corr), int(device)))
+    entry = lib().lslam_icp_batch_f64 if dtype == np.float64 else lib().lslam_icp_batch
+    check(entry(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), src.shape[1], ptr(init_T), S,
+                float(epsilon), float(stopping_thresh), int(max_iters), flags,
+                ptr(out_T), ptr(out_err), ptr(out_it), ptr(corr), int(device)))
     return IcpBatchResult(out_T, out_err, out_it, corr)
 
 
 def icp_batch_dev(d_src, d_src_off, d_tgt, d_tgt_off, dim, d_init_T, S, max_src_n, max_tgt_n,
                   d_out_T, d_out_err, d_out_iters, d_out_corr=None, epsilon=0.01, max_iters=2000,
-                  stopping_thresh=0.0001, normalize_error=False, stream=0, prune=None) -> None:
-    """Same on DEVICE pointers (ints, e.g. torch.Tensor.data_ptr()); enqueues and returns."""
+                  stopping_thresh=0.0001, normalize_error=False, stream=0, prune=None, d_src64=None, d_tgt64=None) -> None:
+    """Same on DEVICE pointers (ints, e.g. torch.Tensor.data_ptr()); enqueues and returns.  ``d_src64`` / ``d_tgt64``:
+    the same clouds in float64 (laid out alike) → float64-exact mode (``lslam_icp_batch_dev64``)."""
     flags = (_lib.ICP_NORMALIZE_ERROR if normalize_error else 0) | _lib.search_flags(prune)
-    check(lib().lslam_icp_batch_dev(d_src, d_src_off, d_tgt, d_tgt_off, int(dim), d_init_T, int(S),
-                                    int(max_src_n), int(max_tgt_n), float(epsilon), float(stopping_thresh),
-                                    int(max_iters), flags, d_out_T, d_out_err, d_out_iters,
-                                    d_out_corr or None, stream or None))
+    check(lib().lslam_icp_batch_dev64(d_src, d_src64 or None, d_src_off, d_tgt, d_tgt64 or None, d_tgt_off, int(dim), d_init_T, int(S),
+                                      int(max_src_n), int(max_tgt_n), float(epsilon), float(stopping_thresh),
+                                      int(max_iters), flags, d_out_T, d_out_err, d_out_iters,
+                                      d_out_corr or None, stream or None))
 
 
 def icp_large_dev(d_src, n, d_tgt, m, dim, init_T, epsilon=0.01, max_iters=2000, stopping_thresh=0.0001,

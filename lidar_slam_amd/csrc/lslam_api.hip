@@ -171,8 +171,8 @@ int lslam_valu_probe(int device, double* out_lane_ops_per_s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-static int icp_batch_dev_impl(const float* d_src, const int64_t* d_src_off, const float* d_tgt,
-                              const int64_t* d_tgt_off, int dim, const double* d_init_T, int32_t S,
+static int icp_batch_dev_impl(const float* d_src, const double* d_src64, const int64_t* d_src_off, const float* d_tgt,
+                              const double* d_tgt64, const int64_t* d_tgt_off, int dim, const double* d_init_T, int32_t S,
                               int64_t max_src_n, int64_t max_tgt_n, double epsilon, double stopping_thresh,
                               int32_t max_iters, uint32_t flags, double* d_out_T, double* d_out_err,
                               int32_t* d_out_iters, int32_t* d_out_corr, void* stream) {
@@ -182,8 +182,10 @@ static int icp_batch_dev_impl(const float* d_src, const int64_t* d_src_off, cons
   if (!d_src || !d_src_off || !d_tgt || !d_tgt_off || !d_init_T || !d_out_T || !d_out_err || !d_out_iters)
     return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
   if (max_src_n < 0 || max_tgt_n <= 0) return fail(LSLAM_ERR_BAD_ARG, "max_src_n/max_tgt_n must be positive");
+  if ((d_src64 == nullptr) != (d_tgt64 == nullptr)) return fail(LSLAM_ERR_BAD_ARG, "float64 clouds: pass both or neither");
   IcpBatchArgs a{};
   a.src = d_src; a.src_off = d_src_off; a.tgt = d_tgt; a.tgt_off = d_tgt_off;
+  a.src64 = d_src64; a.tgt64 = d_tgt64;
   a.init_T = d_init_T; a.out_T = d_out_T; a.out_err = d_out_err; a.out_iters = d_out_iters;
   a.out_corr = d_out_corr;
   a.epsilon = epsilon; a.stopping_thresh = stopping_thresh; a.max_iters = max_iters; a.flags = flags;
@@ -243,24 +245,45 @@ static int icp_batch_dev_impl(const float* d_src, const int64_t* d_src_off, cons
   return LSLAM_OK;
 }
 
-int lslam_icp_batch_dev(const float* d_src, const int64_t* d_src_off, const float* d_tgt,
-                        const int64_t* d_tgt_off, int dim, const double* d_init_T, int32_t S,
-                        int64_t max_src_n, int64_t max_tgt_n, double epsilon, double stopping_thresh,
-                        int32_t max_iters, uint32_t flags, double* d_out_T, double* d_out_err,
-                        int32_t* d_out_iters, int32_t* d_out_corr, void* stream) {
+int lslam_icp_batch_dev64(const float* d_src, const double* d_src64, const int64_t* d_src_off, const float* d_tgt,
+                          const double* d_tgt64, const int64_t* d_tgt_off, int dim, const double* d_init_T, int32_t S,
+                          int64_t max_src_n, int64_t max_tgt_n, double epsilon, double stopping_thresh,
+                          int32_t max_iters, uint32_t flags, double* d_out_T, double* d_out_err,
+                          int32_t* d_out_iters, int32_t* d_out_corr, void* stream) {
   clear_error();
   int rc = ws_fence().enter(static_cast<hipStream_t>(stream));
   if (rc != LSLAM_OK) return rc;
-  rc = icp_batch_dev_impl(d_src, d_src_off, d_tgt, d_tgt_off, dim, d_init_T, S, max_src_n, max_tgt_n, epsilon,
+  rc = icp_batch_dev_impl(d_src, d_src64, d_src_off, d_tgt, d_tgt64, d_tgt_off, dim, d_init_T, S, max_src_n, max_tgt_n, epsilon,
                           stopping_thresh, max_iters, flags, d_out_T, d_out_err, d_out_iters, d_out_corr, stream);
   const int rc2 = ws_fence().leave(static_cast<hipStream_t>(stream));
   return rc != LSLAM_OK ? rc : rc2;
 }
 
-int lslam_icp_batch(const float* src, const int64_t* src_off, const float* tgt, const int64_t* tgt_off,
-                    int dim, const double* init_T, int32_t S, double epsilon, double stopping_thresh,
-                    int32_t max_iters, uint32_t flags, double* out_T, double* out_err,
-                    int32_t* out_iters, int32_t* out_corr, int device) {
+int lslam_icp_batch_dev(const float* d_src, const int64_t* d_src_off, const float* d_tgt,
+                        const int64_t* d_tgt_off, int dim, const double* d_init_T, int32_t S,
+                        int64_t max_src_n, int64_t max_tgt_n, double epsilon, double stopping_thresh,
+                        int32_t max_iters, uint32_t flags, double* d_out_T, double* d_out_err,
+                        int32_t* d_out_iters, int32_t* d_out_corr, void* stream) {
+  return lslam_icp_batch_dev64(d_src, nullptr, d_src_off, d_tgt, nullptr, d_tgt_off, dim, d_init_T, S, max_src_n, max_tgt_n,
+                               epsilon, stopping_thresh, max_iters, flags, d_out_T, d_out_err, d_out_iters, d_out_corr, stream);
+}
+
+extern "C++" {
+static bool all_finite64(const double* v, int64_t count) {
+  const uint64_t* u = reinterpret_cast<const uint64_t*>(v);
+  uint64_t bad = 0;
+  for (int64_t i = 0; i < count; ++i) bad |= ((u[i] & 0x7ff0000000000000ull) == 0x7ff0000000000000ull);
+  return bad == 0;
+}
+
+// host arrays in / out; PT = float (points as they are) or double (float64-exact mode: the float64 clouds are uploaded,
+// rounded to float32 on the device for the search, and decide near ties / feed the moments)
+template <typename PT>
+static int icp_batch_host(const PT* src, const int64_t* src_off, const PT* tgt, const int64_t* tgt_off,
+                          int dim, const double* init_T, int32_t S, double epsilon, double stopping_thresh,
+                          int32_t max_iters, uint32_t flags, double* out_T, double* out_err,
+                          int32_t* out_iters, int32_t* out_corr, int device) {
+  constexpr bool kF64 = sizeof(PT) == sizeof(double);
   clear_error();
   if (dim != 2 && dim != 3) return fail(LSLAM_ERR_BAD_ARG, "dim must be 2 or 3, got %d", dim);
   if (S < 0) return fail(LSLAM_ERR_BAD_ARG, "negative batch size");
@@ -273,9 +296,10 @@ int lslam_icp_batch(const float* src, const int64_t* src_off, const float* tgt, 
   if ((rc = check_offsets(tgt_off, S, "tgt_off", &max_m, &tot_m)) != LSLAM_OK) return rc;
   for (int32_t s = 0; s < S; ++s)
     if (tgt_off[s + 1] == tgt_off[s]) return fail(LSLAM_ERR_EMPTY_TARGET, "problem %d has an empty target cloud", s);
-  if (!all_finite(src + dim * src_off[0], dim * (tot_n - src_off[0])) ||
-      !all_finite(tgt + dim * tgt_off[0], dim * (tot_m - tgt_off[0])))
-    return fail(LSLAM_ERR_NONFINITE, "point clouds must be finite (NaN or Inf found)");
+  bool finite;
+  if constexpr (kF64) finite = all_finite64(src + dim * src_off[0], dim * (tot_n - src_off[0])) && all_finite64(tgt + dim * tgt_off[0], dim * (tot_m - tgt_off[0]));
+  else finite = all_finite(src + dim * src_off[0], dim * (tot_n - src_off[0])) && all_finite(tgt + dim * tgt_off[0], dim * (tot_m - tgt_off[0]));
+  if (!finite) return fail(LSLAM_ERR_NONFINITE, "point clouds must be finite (NaN or Inf found)");
   if (dim == 2)                                           // the planar kernels never materialise z
     for (int32_t s = 0; s < S; ++s) {
       const double* T = init_T + 16 * (size_t)s;
@@ -286,17 +310,20 @@ int lslam_icp_batch(const float* src, const int64_t* src_off, const float* tgt, 
 
   const bool shared = (src == tgt);                       // scan sequence: upload the scans once
   const int64_t up_src = shared ? (tot_n > tot_m ? tot_n : tot_m) : tot_n;
-  const size_t b_src = sizeof(float) * dim * (size_t)up_src;
-  const size_t b_tgt = shared ? 0 : sizeof(float) * dim * (size_t)tot_m;
+  const size_t n_src = (size_t)dim * (size_t)up_src, n_tgt = shared ? 0 : (size_t)dim * (size_t)tot_m;
+  const size_t b_src = sizeof(float) * n_src, b_tgt = sizeof(float) * n_tgt;
+  const size_t b_src64 = kF64 ? sizeof(double) * n_src : 0, b_tgt64 = kF64 ? sizeof(double) * n_tgt : 0;
   const size_t b_off = sizeof(int64_t) * ((size_t)S + 1);
   const size_t b_T = sizeof(double) * 16 * (size_t)S;
   const size_t b_corr = out_corr ? sizeof(int32_t) * (size_t)tot_n : 0;
   Arena& ar = thread_arena();
-  const size_t total = Arena::align(b_src) + Arena::align(b_tgt) + 2 * Arena::align(b_off) + 2 * Arena::align(b_T) +
-                       Arena::align(sizeof(double) * S) + Arena::align(sizeof(int32_t) * S) + Arena::align(b_corr);
+  const size_t total = Arena::align(b_src) + Arena::align(b_tgt) + Arena::align(b_src64) + Arena::align(b_tgt64) + 2 * Arena::align(b_off) +
+                       2 * Arena::align(b_T) + Arena::align(sizeof(double) * S) + Arena::align(sizeof(int32_t) * S) + Arena::align(b_corr);
   if ((rc = ar.reserve(device, total)) != LSLAM_OK) return rc;
   float* d_src = static_cast<float*>(ar.carve(b_src));
   float* d_tgt = shared ? d_src : static_cast<float*>(ar.carve(b_tgt));
+  double* d_src64 = kF64 ? static_cast<double*>(ar.carve(b_src64)) : nullptr;
+  double* d_tgt64 = kF64 ? (shared ? d_src64 : static_cast<double*>(ar.carve(b_tgt64))) : nullptr;
   int64_t* d_so = static_cast<int64_t*>(ar.carve(b_off));
   int64_t* d_to = static_cast<int64_t*>(ar.carve(b_off));
   double* d_iT = static_cast<double*>(ar.carve(b_T));
@@ -307,13 +334,22 @@ int lslam_icp_batch(const float* src, const int64_t* src_off, const float* tgt, 
 
   hipStream_t st;
   if ((rc = thread_stream(&st)) != LSLAM_OK) return rc;
-  LSLAM_HIP_TRY(hipMemcpyAsync(d_src, src, b_src, hipMemcpyHostToDevice, st));
-  if (!shared) LSLAM_HIP_TRY(hipMemcpyAsync(d_tgt, tgt, b_tgt, hipMemcpyHostToDevice, st));
+  if constexpr (kF64) {
+    LSLAM_HIP_TRY(hipMemcpyAsync(d_src64, src, b_src64, hipMemcpyHostToDevice, st));
+    LSLAM_HIP_TRY(launch_f64_to_f32(d_src64, d_src, (int64_t)n_src, st));
+    if (!shared) {
+      LSLAM_HIP_TRY(hipMemcpyAsync(d_tgt64, tgt, b_tgt64, hipMemcpyHostToDevice, st));
+      LSLAM_HIP_TRY(launch_f64_to_f32(d_tgt64, d_tgt, (int64_t)n_tgt, st));
+    }
+  } else {
+    LSLAM_HIP_TRY(hipMemcpyAsync(d_src, src, b_src, hipMemcpyHostToDevice, st));
+    if (!shared) LSLAM_HIP_TRY(hipMemcpyAsync(d_tgt, tgt, b_tgt, hipMemcpyHostToDevice, st));
+  }
   LSLAM_HIP_TRY(hipMemcpyAsync(d_so, src_off, b_off, hipMemcpyHostToDevice, st));
   LSLAM_HIP_TRY(hipMemcpyAsync(d_to, tgt_off, b_off, hipMemcpyHostToDevice, st));
   LSLAM_HIP_TRY(hipMemcpyAsync(d_iT, init_T, b_T, hipMemcpyHostToDevice, st));
-  rc = lslam_icp_batch_dev(d_src, d_so, d_tgt, d_to, dim, d_iT, S, max_n, max_m, epsilon, stopping_thresh,
-                           max_iters, flags, d_oT, d_err, d_it, d_corr, st);
+  rc = lslam_icp_batch_dev64(d_src, d_src64, d_so, d_tgt, d_tgt64, d_to, dim, d_iT, S, max_n, max_m, epsilon, stopping_thresh,
+                             max_iters, flags, d_oT, d_err, d_it, d_corr, st);
   if (rc != LSLAM_OK) return rc;
   LSLAM_HIP_TRY(hipMemcpyAsync(out_T, d_oT, b_T, hipMemcpyDeviceToHost, st));
   LSLAM_HIP_TRY(hipMemcpyAsync(out_err, d_err, sizeof(double) * S, hipMemcpyDeviceToHost, st));
@@ -321,6 +357,23 @@ int lslam_icp_batch(const float* src, const int64_t* src_off, const float* tgt, 
   if (out_corr) LSLAM_HIP_TRY(hipMemcpyAsync(out_corr, d_corr, b_corr, hipMemcpyDeviceToHost, st));
   LSLAM_HIP_TRY(hipStreamSynchronize(st));
   return LSLAM_OK;
+}
+}  // extern "C++"
+
+int lslam_icp_batch(const float* src, const int64_t* src_off, const float* tgt, const int64_t* tgt_off,
+                    int dim, const double* init_T, int32_t S, double epsilon, double stopping_thresh,
+                    int32_t max_iters, uint32_t flags, double* out_T, double* out_err,
+                    int32_t* out_iters, int32_t* out_corr, int device) {
+  return icp_batch_host<float>(src, src_off, tgt, tgt_off, dim, init_T, S, epsilon, stopping_thresh, max_iters, flags,
+                               out_T, out_err, out_iters, out_corr, device);
+}
+
+int lslam_icp_batch_f64(const double* src, const int64_t* src_off, const double* tgt, const int64_t* tgt_off,
+                        int dim, const double* init_T, int32_t S, double epsilon, double stopping_thresh,
+                        int32_t max_iters, uint32_t flags, double* out_T, double* out_err,
+                        int32_t* out_iters, int32_t* out_corr, int device) {
+  return icp_batch_host<double>(src, src_off, tgt, tgt_off, dim, init_T, S, epsilon, stopping_thresh, max_iters, flags,
+                                out_T, out_err, out_iters, out_corr, device);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -965,8 +1018,9 @@ int lslam_scans_match_sequence(void* scans, const double* init_T, double epsilon
   if ((rc = thread_stream(&st)) != LSLAM_OK) return rc;
   LSLAM_HIP_TRY(hipMemcpyAsync(d_iT, init_T, b_T, hipMemcpyHostToDevice, st));
   // source = scan s+1, target = scan s (localization.py:120-121): the same buffer with shifted offsets
-  rc = lslam_icp_batch_dev(z->d_xy32, z->d_off + 1, z->d_xy32, z->d_off, 2, d_iT, (int32_t)S, z->max_n, z->max_n, epsilon,
-                           stopping_thresh, max_iters, flags, d_oT, d_err, d_it, nullptr, st);
+  // both copies of the points are resident: float64-exact mode
+  rc = lslam_icp_batch_dev64(z->d_xy32, z->d_xy64, z->d_off + 1, z->d_xy32, z->d_xy64, z->d_off, 2, d_iT, (int32_t)S, z->max_n, z->max_n,
+                             epsilon, stopping_thresh, max_iters, flags, d_oT, d_err, d_it, nullptr, st);
   if (rc != LSLAM_OK) return rc;
   LSLAM_HIP_TRY(hipMemcpyAsync(out_T, d_oT, b_T, hipMemcpyDeviceToHost, st));
   LSLAM_HIP_TRY(hipMemcpyAsync(out_err, d_err, sizeof(double) * S, hipMemcpyDeviceToHost, st));

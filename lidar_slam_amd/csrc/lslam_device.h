@@ -147,20 +147,59 @@ __device__ __forceinline__ void filter_track(float mc, int c, float& b1, float& 
   i1 = lt1 ? c : i1;
 }
 
+// ---- float64-exact mode: near ties of the float32 search are decided in float64 ---------------------
+// The reference searches in float64 (modules/icp.py:29-41).  When the caller also hands over the float64 clouds, the
+// float32 search is only a candidate generator: with a_d = T·p_d, t_d the float64 points and a_f, t_f what the sweep
+// sees, |(a_d − t_d) − (a_f − t_f)| ≤ ε = 1.001·u·(|a| + F·Rs + Rt)  (u = 2⁻²⁴, Rs / Rt = largest |p| / |t| of the
+// problem, F = Frobenius norm of T's linear block ≥ its spectral norm; |a| ≤ Rt + d̂).  If ĵ is the float32 winner
+// with recipe value D̂, the float64 winner j* (and every float64 tie of it) has a recipe value
+//     D(j*) ≤ lim(D̂) = (√D̂·(1 + 4u) + 2ε)²·(1 + 8u)
+// so only targets with D ≤ lim(D̂) are re-evaluated in float64 — usually none besides ĵ.  With the mode off lim(D) = D
+// and K1 = 1, C = 0: every comparison below is then bit for bit the float32-only rule.
+struct NearTie {
+  float eps0;                // 1.001·u·(2 Rt + F·Rs): the part of ε that does not depend on the distance
+  float K1, C;               // lim(D) ≤ K1·D + C for every D: the slack of the pruning tests (no square root there)
+  bool on;
+};
+__device__ __forceinline__ NearTie near_tie_setup(bool on, float Rt, float Rs, float F) {
+  NearTie nt;
+  nt.on = on;
+  nt.eps0 = 0.f; nt.K1 = 1.f; nt.C = 0.f;
+  if (on) {
+    constexpr float kU = 5.97e-8f;
+    nt.eps0 = 1.001f * kU * (2.f * Rt + F * Rs);
+    // 4 ε d ≤ κ d² + 4 ε²/κ with κ = 2⁻⁹; ε² ≤ 2 ε0² + 2.01 u² D
+    nt.K1 = 1.f + 0.001953125f + 1e-5f;
+    nt.C = 8.1f * 513.f * nt.eps0 * nt.eps0 + 1e-36f;
+  }
+  return nt;
+}
+__device__ __forceinline__ float near_lim(float D, const NearTie& nt) {
+  if (!nt.on) return D;
+  const float d = sqrtf(D) * 1.000001f;
+  const float x = d + 2.f * (nt.eps0 + 6.0e-8f * d);
+  return x * x * 1.000002f + 1e-37f;
+}
+
 // After the sweep: does the second chunk have to be re-evaluated (`two`), and is a third chunk (or an overflow risk)
 // in play so that the exact sweep must run instead (`third`)?  Rt ≥ the largest |t| swept.  Every comparison is
-// written so that a NaN sends the caller to the exact sweep.
+// written so that a NaN sends the caller to the exact sweep.  In float64-exact mode the chunks kept must hold every
+// target within lim(D̂) of the winner, not only the winner: τ grows by lim(d²) − d² (+ 2u·d² for the roundings of lim's
+// argument), see DESIGN.md §3.1d.
 template <int DIM>
-__device__ __forceinline__ void filter_decide(const float (&a)[DIM], float Rt, float b1, float b2, float b3, bool& two, bool& third) {
+__device__ __forceinline__ void filter_decide(const float (&a)[DIM], float Rt, float b1, float b2, float b3, const NearTie& nt, bool& two, bool& third) {
   constexpr float kU = 5.97e-8f;                             // > 2⁻²⁴
   constexpr float kE = (DIM == 2 ? 4.5f : 6.5f) * kU;
+  // the direct recipe rounds the x term four times in the plane (|θ| ≤ 4.01u), five times in space (5.01u): 2θ + margins
+  constexpr float kD = (DIM == 2 ? 9.f : 11.f) * kU;
   float a2;
   if constexpr (DIM == 2) a2 = __builtin_fmaf(a[1], a[1], a[0] * a[0]);
   else a2 = __builtin_fmaf(a[2], a[2], __builtin_fmaf(a[1], a[1], a[0] * a[0]));
   const float an = sqrtf(a2) * 1.0001f;
   const float E = kE * Rt * (Rt + an);
   const float d2 = fmaxf((b1 + a2) * 1.000001f + E + 3.f * kU * a2, 0.f);       // ≥ |a − t|² of the filter's winner
-  const float tau = (2.f * E + 9.f * kU * d2) * 1.001f + 1e-30f;
+  float tau = (2.f * E + kD * d2) * 1.001f + 1e-30f;
+  if (nt.on) tau += (near_lim(d2, nt) - d2) * 1.0001f + 2.f * kU * d2;
   const float lim = b1 + tau;
   two = !(b2 > lim);
   third = !(b3 > lim) || !(Rt < 1e15f) || !(an < 1e15f);

@@ -59,11 +59,12 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ g, int64_t 
 
 // ---- the all-pairs sweep over one LDS tile ----------------------------------------------------
 // best[p]: smallest distance seen so far; bchunk[p]: global chunk id holding it (strict '<', so
-// the earliest chunk wins ties).
-template <int DIM, int P, int CHUNK>
+// the earliest chunk wins ties); second[p]: the second smallest chunk minimum (float64-exact mode: is another
+// chunk within reach of a near tie?).
+template <int DIM, int P, int CHUNK, bool SEC>
 __device__ __forceinline__ void sweep_tile(const typename TilePoint<DIM>::type* tile, int nchunks,
                                            int chunk_base, const float (&a)[P][DIM],
-                                           float (&best)[P], int (&bchunk)[P]) {
+                                           float (&best)[P], float (&second)[P], int (&bchunk)[P]) {
   if constexpr (DIM == 2) {
     // a record step (min, chunk id) covers CHUNK targets; they are loaded LOAD at a time so that a
     // 32-target chunk does not need 64 registers of target data
@@ -93,6 +94,7 @@ __device__ __forceinline__ void sweep_tile(const typename TilePoint<DIM>::type* 
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const bool lt = m[p] < best[p];
+        if constexpr (SEC) second[p] = __builtin_amdgcn_fmed3f(best[p], second[p], m[p]);      // second smallest chunk minimum (best ≤ second holds)
         bchunk[p] = lt ? (chunk_base + c) : bchunk[p];
         best[p] = fminf(best[p], m[p]);
       }
@@ -113,6 +115,7 @@ __device__ __forceinline__ void sweep_tile(const typename TilePoint<DIM>::type* 
         }
         m = fminf(m, dist2(a[p][0], a[p][1], a[p][2], v[CHUNK - 1].x, v[CHUNK - 1].y, v[CHUNK - 1].z));
         const bool lt = m < best[p];
+        if constexpr (SEC) second[p] = __builtin_amdgcn_fmed3f(best[p], second[p], m);
         bchunk[p] = lt ? (chunk_base + c) : bchunk[p];
         best[p] = fminf(best[p], m);
       }
@@ -158,9 +161,9 @@ __device__ __forceinline__ void filter_sweep(const typename TilePoint<DIM>::type
 // exact distances of the targets of one filter chunk: minimum of the 64-bit key (distance bits, index) — distances
 // are non-negative floats, whose order is the order of their bit patterns, so one unsigned compare is the
 // lexicographic (distance, lowest index) rule
-template <int DIM>
+template <int DIM, bool SEC>
 __device__ __forceinline__ void exact_chunk(const typename TilePoint<DIM>::type* tile, int chunk, int lane, const float (&a)[DIM],
-                                            unsigned long long& best) {
+                                            unsigned long long& best, float& bd, float& sec) {
   using TP = typename TilePoint<DIM>::type;
   const int j0 = chunk * kFilterChunk;
   // opaque copy of the lane id: otherwise the 32 rotated offsets are hoisted out of the ICP loop as 32 live
@@ -175,10 +178,14 @@ __device__ __forceinline__ void exact_chunk(const typename TilePoint<DIM>::type*
     else d = dist2(a[0], a[1], a[2], v.x, v.y, v.z);
     const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
     best = key < best ? key : best;
+    if constexpr (SEC) {                                     // float64-exact mode: smallest and second smallest distance seen (a near tie?)
+      sec = __builtin_amdgcn_fmed3f(bd, sec, d);
+      bd = fminf(bd, d);
+    }
   }
 }
 
-template <int DIM, int P, int CHUNK, bool FILTER>
+template <int DIM, int P, int CHUNK, bool FILTER, bool F64>
 __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
   using TP = typename TilePoint<DIM>::type;
   constexpr int kAcc = AccLayout<DIM>::kTotal;
@@ -207,9 +214,13 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
   const float* __restrict__ gsrc = args.src + (int64_t)DIM * s0;
   const float* __restrict__ gtgt = args.tgt + (int64_t)DIM * t0;
   const bool box = (args.flags & kFlagNormalize) != 0;
+  // float64-exact mode (lslam_device.h: NearTie): the same clouds in float64 decide near ties and feed the moments
+  constexpr bool f64 = F64;                                     // the launcher picks the F64 builds when args.src64 is set
+  const double* __restrict__ gsrc64 = f64 ? args.src64 + (int64_t)DIM * s0 : nullptr;
+  const double* __restrict__ gtgt64 = f64 ? args.tgt64 + (int64_t)DIM * t0 : nullptr;
 
   if (tid < 16) sh_T[tid] = args.init_T[(int64_t)16 * pair + tid];
-  if (FILTER && tid == 0) sh_flag[1] = 0;
+  if (tid == 0) { sh_flag[1] = 0; sh_flag[2] = 0; sh_flag[3] = 0; }       // bits of max |t|², max |p|² (non-negative floats order like their bits)
 
   const int tile_cap = args.tile_points;                       // multiple of CHUNK (and of kFilterChunk in the FILTER build)
   const int ntiles = (m + tile_cap - 1) / tile_cap;
@@ -251,8 +262,31 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, kWave));
     if (lane == 0) atomicMax(&sh_flag[1], __float_as_int(wmax));      // non-negative floats order like their bits
+  }
+  float Rs = 0.f;                                              // ≥ the largest |p| of the problem (float64-exact mode)
+  if (f64) {
+    float smax = 0.f, tmax = 0.f;
+    for (int i = tid; i < n; i += blockDim.x) {
+      float w = 0.f;
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) { const float c = gsrc[(int64_t)DIM * i + r]; w = __builtin_fmaf(c, c, w); }
+      smax = fmaxf(smax, w);
+    }
+    if constexpr (!FILTER)
+      for (int j = tid; j < m; j += blockDim.x) {
+        float w = 0.f;
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) { const float c = gtgt[(int64_t)DIM * j + r]; w = __builtin_fmaf(c, c, w); }
+        tmax = fmaxf(tmax, w);
+      }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) { smax = fmaxf(smax, __shfl_xor(smax, o, kWave)); tmax = fmaxf(tmax, __shfl_xor(tmax, o, kWave)); }
+    if (lane == 0) { atomicMax(&sh_flag[2], __float_as_int(smax)); if (!FILTER) atomicMax(&sh_flag[1], __float_as_int(tmax)); }
+  }
+  if (FILTER || f64) {
     __syncthreads();
     Rt = sqrtf(__int_as_float(sh_flag[1])) * 1.0001f;
+    Rs = sqrtf(__int_as_float(sh_flag[2])) * 1.0001f;
   }
 
   if (tid == 0) { StopState st0; stop_init(st0); *sh_stop = st0; *sh_err = 0.0; }       // read first after the barrier that precedes the solve
@@ -262,7 +296,7 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
   // One pass = blockDim·P source points: transform, sweep all targets, fix up the index, add the
   // pair to the float64 moments.  Only the float32 copies of the points live across the sweep;
   // the float64 transform is re-evaluated afterwards from the (L2-resident) source.
-  auto run_pass = [&](int base, const double (&T)[3][4], PairAcc<DIM>& acc) {
+  auto run_pass = [&](int base, const double (&T)[3][4], const NearTie& nt, PairAcc<DIM>& acc) {
     // waves whose first lane is already past the last source point skip the sweep and the fix-up
     // (scans of a batch differ in size; the launch is sized for the largest)
     const bool wave_live = base + (tid & ~(kWave - 1)) * P < n;
@@ -283,6 +317,59 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
     int bi[P];                                               // matched target index and its coordinates
     float q[P][DIM];
     bool matched = false;
+
+    // ---- float64-exact mode: the targets whose float32 distance is within lim of the winner's are compared in float64.
+    // scope (per lane) 0: nothing to do; 1: chunk cA; 2: chunks cA and cB; 3: any target.  csz = targets per chunk.
+    // Wave-uniform loops with broadcast (or rotated) reads; the float64 evaluation sits in a rare divergent branch.
+    auto refine_point = [&](const float (&ap)[DIM], int i, float lim, int scope, int cA, int cB, int csz, int& bj) {
+      if (!__any(scope != 0)) return;
+      double ad[DIM];
+      if (scope) {
+        double x, y, z = 0.0;
+        x = gsrc64[(int64_t)DIM * i]; y = gsrc64[(int64_t)DIM * i + 1];
+        if constexpr (DIM == 3) z = gsrc64[(int64_t)DIM * i + 2];
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) {                        // icp.py:116 on the float64 point
+          double v = T[r][0] * x + T[r][1] * y + T[r][3];
+          if constexpr (DIM == 3) v += T[r][2] * z;
+          ad[r] = v;
+        }
+      }
+      double bv = INFINITY;
+      int bjn = bj;
+      auto look = [&](int j) {
+        float bx, by, bz = 0.f;
+        if (resident) {
+          const TP v = tile[j];
+          bx = v.x; by = v.y;
+          if constexpr (DIM == 3) bz = v.z;
+        } else {
+          const bool in = j < m;
+          bx = in ? gtgt[(int64_t)DIM * j] : kFar;
+          by = in ? gtgt[(int64_t)DIM * j + 1] : kFar;
+          if constexpr (DIM == 3) bz = in ? gtgt[(int64_t)DIM * j + 2] : kFar;
+        }
+        float d;
+        if constexpr (DIM == 2) d = dist2(ap[0], ap[1], bx, by);
+        else d = dist2(ap[0], ap[1], ap[2], bx, by, bz);
+        if (scope && d <= lim) {                               // rare: a candidate of this lane
+          double e = 0.0;
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) { const double df = ad[r] - gtgt64[(int64_t)DIM * j + r]; e += df * df; }
+          if (e < bv || (e == bv && j < bjn)) { bv = e; bjn = j; }
+        }
+      };
+      if (__any(scope == 3)) {
+        for (int j = 0; j < m; ++j) look(j);
+      } else {
+        int rot = lane;
+        asm volatile("" : "+v"(rot));
+        for (int kk = 0; kk < csz; ++kk) look(cA * csz + ((kk + rot) & (csz - 1)));
+        if (__any(scope == 2))
+          for (int kk = 0; kk < csz; ++kk) look(cB * csz + ((kk + rot) & (csz - 1)));
+      }
+      if (scope) bj = bjn;
+    };
 
     // ---- FILTER build: expanded-form sweep, then the exact recipe on the chunks that can hold the winner ----
     if constexpr (FILTER) {
@@ -307,7 +394,7 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           bool third;
-          filter_decide<DIM>(a[p], Rt, b1[p], b2[p], b3[p], two[p], third);
+          filter_decide<DIM>(a[p], Rt, b1[p], b2[p], b3[p], nt, two[p], third);
           fall |= (base + tid * P + p < n) && third;
         }
         f_tries++;
@@ -319,13 +406,22 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
 #pragma unroll
           for (int p = 0; p < P; ++p) {
             unsigned long long k1 = ~0ull;
-            exact_chunk<DIM>(tile, i1[p], lane, a[p], k1);
+            float bd = INFINITY, sec = INFINITY;
+            exact_chunk<DIM, F64>(tile, i1[p], lane, a[p], k1, bd, sec);
             if (__any(two[p])) {
               unsigned long long k2 = k1;
-              exact_chunk<DIM>(tile, i2[p], lane, a[p], k2);
+              float bd2 = bd, sec2 = sec;
+              exact_chunk<DIM, F64>(tile, i2[p], lane, a[p], k2, bd2, sec2);
               k1 = two[p] ? k2 : k1;
+              bd = two[p] ? bd2 : bd;
+              sec = two[p] ? sec2 : sec;
             }
             bi[p] = (int)(unsigned)k1;
+            if constexpr (F64) {                               // every target within lim of the winner lies in these chunks (τ was widened)
+              const int i = base + tid * P + p;
+              const float lim = near_lim(bd, nt);
+              refine_point(a[p], i, lim, (i < n && sec <= lim) ? (two[p] ? 2 : 1) : 0, i1[p], i2[p], kFilterChunk, bi[p]);
+            }
             const TP v = tile[bi[p]];
             q[p][0] = v.x; q[p][1] = v.y;
             if constexpr (DIM == 3) q[p][2] = v.z;
@@ -337,12 +433,12 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
 
     if (!matched) {
       // ---- nearest neighbour over all targets, exact recipe ----------------------------------------
-      float best[P];
+      float best[P], second[P];
       int bchunk[P];
 #pragma unroll
-      for (int p = 0; p < P; ++p) { best[p] = INFINITY; bchunk[p] = 0; }
+      for (int p = 0; p < P; ++p) { best[p] = INFINITY; second[p] = INFINITY; bchunk[p] = 0; }
       if (resident) {
-        if (wave_live) sweep_tile<DIM, P, CHUNK>(tile, (m + CHUNK - 1) / CHUNK, 0, a, best, bchunk);
+        if (wave_live) sweep_tile<DIM, P, CHUNK, F64>(tile, (m + CHUNK - 1) / CHUNK, 0, a, best, second, bchunk);
       } else {
         for (int t = 0; t < ntiles; ++t) {
           const int first = t * tile_cap;
@@ -350,7 +446,7 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
           __syncthreads();                                     // previous tile fully consumed
           stage_tile<DIM>(gtgt + (int64_t)DIM * first, cnt, ((cnt + CHUNK - 1) / CHUNK) * CHUNK, tile);
           __syncthreads();
-          if (wave_live) sweep_tile<DIM, P, CHUNK>(tile, (cnt + CHUNK - 1) / CHUNK, first / CHUNK, a, best, bchunk);
+          if (wave_live) sweep_tile<DIM, P, CHUNK, F64>(tile, (cnt + CHUNK - 1) / CHUNK, first / CHUNK, a, best, second, bchunk);
         }
       }
 
@@ -361,7 +457,7 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int j0 = bchunk[p] * CHUNK;
-        float bd = INFINITY;
+        float bd = INFINITY, sec2 = INFINITY;                  // smallest and second smallest distance inside the chunk
         bi[p] = j0;
 #pragma unroll
         for (int r = 0; r < DIM; ++r) q[p][r] = 0.f;
@@ -385,10 +481,17 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
           float d;
           if constexpr (DIM == 2) d = dist2(a[p][0], a[p][1], bx, by);
           else d = dist2(a[p][0], a[p][1], a[p][2], bx, by, bz);
+          if constexpr (F64) sec2 = __builtin_amdgcn_fmed3f(bd, sec2, d);
           if (kk == 0 || d < bd || (d == bd && j < bi[p])) {      // lowest index on ties, whatever the visiting order
             bd = d; bi[p] = j; q[p][0] = bx; q[p][1] = by;
             if constexpr (DIM == 3) q[p][2] = bz;
           }
+        }
+        if constexpr (F64) {
+          const int i = base + tid * P + p;
+          const float lim = near_lim(bd, nt);
+          const int scope = (i < n) ? (second[p] <= lim ? 3 : (sec2 <= lim ? 1 : 0)) : 0;
+          refine_point(a[p], i, lim, scope, bchunk[p], 0, CHUNK, bi[p]);
         }
       }
     }
@@ -399,14 +502,22 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
       const int i = base + tid * P + p;
       if (i < n) {
         double x, y, z = 0.0;
-        load_src(i, x, y, z);
         double pd[DIM], qd[DIM];
+        if (f64) {                                             // the float64 points themselves: icp.py:116-118 as the reference computes them
+          x = gsrc64[(int64_t)DIM * i]; y = gsrc64[(int64_t)DIM * i + 1];
+          if constexpr (DIM == 3) z = gsrc64[(int64_t)DIM * i + 2];
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) qd[r] = gtgt64[(int64_t)DIM * bi[p] + r];
+        } else {
+          load_src(i, x, y, z);
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) qd[r] = (double)q[p][r];
+        }
 #pragma unroll
         for (int r = 0; r < DIM; ++r) {
           double v = T[r][0] * x + T[r][1] * y + T[r][3];
           if constexpr (DIM == 3) v += T[r][2] * z;
           pd[r] = v;
-          qd[r] = (double)q[p][r];
         }
         acc.add(pd, qd, box);
         if (args.out_corr) args.out_corr[s0 + i] = bi[p];
@@ -422,13 +533,25 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) T[r][c] = wave_uniform(sh_T[4 * r + c]);
 
+    // float64-exact mode: the near-tie window of this iteration (F = Frobenius norm of T's linear block)
+    float Fn = 0.f;
+    if (f64) {
+      double f2 = 0.0;
+#pragma unroll
+      for (int r = 0; r < DIM; ++r)
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) f2 += T[r][c] * T[r][c];
+      Fn = sqrtf((float)f2) * 1.0001f;
+    }
+    const NearTie nt = near_tie_setup(f64, Rt, Rs, Fn);
+
     PairAcc<DIM> acc;
     acc.clear();
     const int passes = n > 0 ? (n + src_per_pass - 1) / src_per_pass : 1;
     if (passes == 1) {
-      run_pass(0, T, acc);               // common case: the zeroed accumulators never live across the sweep
+      run_pass(0, T, nt, acc);           // common case: the zeroed accumulators never live across the sweep
     } else {
-      for (int pass = 0; pass < passes; ++pass) run_pass(pass * src_per_pass, T, acc);
+      for (int pass = 0; pass < passes; ++pass) run_pass(pass * src_per_pass, T, nt, acc);
     }
 
     // ---- block reduction: wave rows → LDS → wave 0 combines and solves -----------------------
@@ -489,41 +612,49 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
 //                           chunk: LiDAR-sized problems (≤ ~1000 points) leave most of an iteration's
 //                           wall time in barriers and the one-lane solve, so several workgroups must
 //                           be resident per CU to keep the VALUs fed.
-template <int DIM, int P>
+template <int DIM, int P, bool F64>
 __global__ void __launch_bounds__(kIcpBatchMaxThreads)
 icp_batch_kernel(IcpBatchArgs args) {
-  icp_batch_body<DIM, P, IcpChunk<DIM>::value, false>(args);
+  icp_batch_body<DIM, P, IcpChunk<DIM>::value, false, F64>(args);
 }
 
 // the big build with the expanded-form filter sweep in front of the exact recipe (target resident in LDS)
-template <int DIM, int P>
+template <int DIM, int P, bool F64>
 __global__ void __launch_bounds__(kIcpBatchMaxThreads)
 icp_batch_filter_kernel(IcpBatchArgs args) {
-  icp_batch_body<DIM, P, IcpChunk<DIM>::value, true>(args);
+  icp_batch_body<DIM, P, IcpChunk<DIM>::value, true, F64>(args);
 }
 
-template <int DIM, int P>
+template <int DIM, int P, bool F64>
 __global__ void __launch_bounds__(kIcpSmallMaxThreads, 8)
 icp_batch_small_kernel(IcpBatchArgs args) {
-  icp_batch_body<DIM, P, IcpChunkSmall<DIM>::value, false>(args);
+  icp_batch_body<DIM, P, IcpChunkSmall<DIM>::value, false, F64>(args);
 }
 
 // ---- launch ------------------------------------------------------------------------------------
 enum class Build { kBig, kSmall, kFilter };
 
-template <int DIM, int P>
-static hipError_t launch_one(const IcpBatchArgs& a, int S, int threads, size_t smem, Build build, hipStream_t stream) {
-  const void* fn = build == Build::kSmall ? reinterpret_cast<const void*>(icp_batch_small_kernel<DIM, P>)
-                 : build == Build::kFilter ? reinterpret_cast<const void*>(icp_batch_filter_kernel<DIM, P>)
-                                           : reinterpret_cast<const void*>(icp_batch_kernel<DIM, P>);
+template <int DIM, int P, bool F64>
+static hipError_t launch_one_mode(const IcpBatchArgs& a, int S, int threads, size_t smem, Build build, hipStream_t stream) {
+  const void* fn = build == Build::kSmall ? reinterpret_cast<const void*>(icp_batch_small_kernel<DIM, P, F64>)
+                 : build == Build::kFilter ? reinterpret_cast<const void*>(icp_batch_filter_kernel<DIM, P, F64>)
+                                           : reinterpret_cast<const void*>(icp_batch_kernel<DIM, P, F64>);
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
   }
-  if (build == Build::kSmall) hipLaunchKernelGGL((icp_batch_small_kernel<DIM, P>), dim3(S), dim3(threads), smem, stream, a);
-  else if (build == Build::kFilter) hipLaunchKernelGGL((icp_batch_filter_kernel<DIM, P>), dim3(S), dim3(threads), smem, stream, a);
-  else hipLaunchKernelGGL((icp_batch_kernel<DIM, P>), dim3(S), dim3(threads), smem, stream, a);
+  if (build == Build::kSmall) hipLaunchKernelGGL((icp_batch_small_kernel<DIM, P, F64>), dim3(S), dim3(threads), smem, stream, a);
+  else if (build == Build::kFilter) hipLaunchKernelGGL((icp_batch_filter_kernel<DIM, P, F64>), dim3(S), dim3(threads), smem, stream, a);
+  else hipLaunchKernelGGL((icp_batch_kernel<DIM, P, F64>), dim3(S), dim3(threads), smem, stream, a);
   return hipGetLastError();
+}
+
+// the float64-exact builds exist for 1, 2 and 4 points per lane (the launcher never picks 8 in that mode)
+template <int DIM, int P>
+static hipError_t launch_one(const IcpBatchArgs& a, int S, int threads, size_t smem, Build build, hipStream_t stream) {
+  if constexpr (P <= 4)
+    if (a.src64) return launch_one_mode<DIM, P, true>(a, S, threads, smem, build, stream);
+  return launch_one_mode<DIM, P, false>(a, S, threads, smem, build, stream);
 }
 
 hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, int64_t max_tgt_n,
@@ -531,7 +662,8 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
   // points per lane
   int P = tune.points_per_lane;
   if (P == 0) P = (max_src_n <= 512) ? 1 : ((max_src_n <= 2048) ? 2 : 4);
-  if (P != 1 && P != 2 && P != 4 && !(P == 8 && dim == 2)) return hipErrorInvalidValue;
+  if (P != 1 && P != 2 && P != 4 && !(P == 8 && dim == 2 && !a.src64)) return hipErrorInvalidValue;
+  if ((a.src64 == nullptr) != (a.tgt64 == nullptr)) return hipErrorInvalidValue;
   int64_t lanes = (max_src_n + P - 1) / P;
   int threads = (int)(((lanes + kWave - 1) / kWave) * kWave);
   if (threads < kWave) threads = kWave;
@@ -557,7 +689,7 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
   // instead of one of 16.  It pays only while every CU always holds two problems (tools/p8_crossover.sh,
   // profiles/r02/p8_crossover.txt: 194 vs 210 ms on C4, 49 vs 53 ms at 8192 points, but 12.5 vs 11.5 ms for 512
   // problems and 15.5 vs 10.9 ms at 2600 points).
-  if (filter && dim == 2 && tune.points_per_lane == 0 && tune.threads == 0 && max_src_n >= 3584 && S >= 2048) {
+  if (filter && dim == 2 && !a.src64 && tune.points_per_lane == 0 && tune.threads == 0 && max_src_n >= 3584 && S >= 2048) {
     P = 8;
     lanes = (max_src_n + P - 1) / P;
     threads = (int)(((lanes + kWave - 1) / kWave) * kWave);

@@ -358,7 +358,7 @@ nn_tiled_filter_kernel(NnArgs a) {
 #pragma unroll
     for (int r = 0; r < DIM; ++r) s[p][r] = -0.5f * na[p][r];      // exact
     bool third;
-    filter_decide<DIM>(s[p], Rt, b1[p], b2[p], b3[p], two[p], third);
+    filter_decide<DIM>(s[p], Rt, b1[p], b2[p], b3[p], near_tie_setup(false, 0.f, 0.f, 0.f), two[p], third);
     fall |= (base + (int64_t)p * kNnThreads + tid < a.n) && third;
   }
 

@@ -142,7 +142,9 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2) {
   }
 }
 
-template <int P>
+// F64: the float64-exact mode (lslam_device.h: NearTie; args.src64 / args.tgt64 set) — pruning and tie detection use the
+// near-tie window lim(D) instead of D, near ties are decided on the float64 points, the moments are taken from them.
+template <int P, bool F64>
 __global__ void __launch_bounds__(kIcpBatchMaxThreads, 8)      // ≤ 64 VGPRs: two 16-wave workgroups per CU (measured 1.3× faster than 119 VGPRs / one workgroup)
 icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   constexpr int CHUNK = kPruneChunk;
@@ -171,11 +173,30 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   const bool box = (args.flags & kFlagNormalize) != 0;
   const int nchunks = (m + CHUNK - 1) / CHUNK;
 
+  const double* __restrict__ gsrc64 = F64 ? args.src64 + 2 * s0 : nullptr;          // original order, like args.src
+  const double* __restrict__ gtgt64 = F64 ? args.tgt64 + 2 * t0 : nullptr;
+  const uint16_t* __restrict__ sidx = sc.src_index + ss;     // original index of a sorted source
   if (tid < 16) sh_T[tid] = args.init_T[(int64_t)16 * pair + tid];
-  for (int j = tid; j < nchunks * CHUNK; j += blockDim.x) tile[j] = (j < m) ? sc.tgt_sorted[ts + j] : make_float2(kFar, kFar);
+  if (F64 && tid == 0) { sh_flag[1] = 0; sh_flag[2] = 0; }   // bits of max |t|², max |p|²
+  float tmax = 0.f, smax = 0.f;
+  for (int j = tid; j < nchunks * CHUNK; j += blockDim.x) {
+    const float2 v = (j < m) ? sc.tgt_sorted[ts + j] : make_float2(kFar, kFar);
+    tile[j] = v;
+    if (F64 && j < m) tmax = fmaxf(tmax, __builtin_fmaf(v.y, v.y, v.x * v.x));
+  }
   const bool src_lds = lay.src_off != 0xffffffffu;
-  for (int i = tid; i < n; i += blockDim.x) { if (src_lds) sh_src[i] = ssrc[i]; sh_prev[i] = 0xffff; }
+  for (int i = tid; i < n; i += blockDim.x) {
+    const float2 v = ssrc[i];
+    if (src_lds) sh_src[i] = v;
+    sh_prev[i] = 0xffff;
+    if (F64) smax = fmaxf(smax, __builtin_fmaf(v.y, v.y, v.x * v.x));
+  }
   __syncthreads();
+  float Rt = 0.f, Rs = 0.f;
+  if constexpr (F64) {
+    tmax = wave_max_f(tmax); smax = wave_max_f(smax);
+    if (lane == 0) { atomicMax(&sh_flag[1], __float_as_int(tmax)); atomicMax(&sh_flag[2], __float_as_int(smax)); }
+  }
   for (int c = tid; c < nchunks; c += blockDim.x) {        // boxes over the real points only
     float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
     for (int k = 0; k < CHUNK && c * CHUNK + k < m; ++k) {
@@ -185,6 +206,10 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
     aabb[c] = make_float4(x0, y0, x1, y1);
   }
   __syncthreads();
+  if constexpr (F64) {
+    Rt = sqrtf(__int_as_float(sh_flag[1])) * 1.0001f;
+    Rs = sqrtf(__int_as_float(sh_flag[2])) * 1.0001f;
+  }
   if (tid == 0) { StopState st0; stop_init(st0); *sh_stop = st0; *sh_err = 0.0; }       // read first after the barrier that precedes the solve
   const int per_pass = blockDim.x * P;
   const int passes = n > 0 ? (n + per_pass - 1) / per_pass : 1;
@@ -195,6 +220,11 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) T[r][c] = wave_uniform(sh_T[4 * r + c]);
+    NearTie nt = near_tie_setup(false, 0.f, 0.f, 0.f);
+    if constexpr (F64)
+      nt = near_tie_setup(true, Rt, Rs, sqrtf((float)(T[0][0] * T[0][0] + T[0][1] * T[0][1] + T[1][0] * T[1][0] + T[1][1] * T[1][1])) * 1.0001f);
+    // the bound a chunk must beat: the lane's best itself, or in float64-exact mode everything within its near-tie window
+    auto reach = [&](float b) { return F64 ? __builtin_fmaf(b, nt.K1, nt.C) : b; };
 
     // ---- phase A: nearest neighbours (float32); the matches go to LDS (they also seed the next iteration)
     for (int pass = 0; pass < passes; ++pass) {
@@ -229,14 +259,18 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
           const int pv = sh_prev[i];
           if (pv != 0xffff) {
             const float2 q = tile[pv];
-            best[p] = next_up(dist2(ax[p], ay[p], q.x, q.y));      // a bound, not yet a candidate: its chunk will beat it strictly
+            // a bound, not yet a candidate: its chunk will beat it strictly (float64-exact mode: by more than the near-tie window,
+            // so that the bound itself is never mistaken for a second candidate)
+            const float ds = dist2(ax[p], ay[p], q.x, q.y);
+            best[p] = F64 ? next_up(reach(ds) * 1.000001f) : next_up(ds);
             bchunk[p] = pv / CHUNK;
           } else {
             // first iteration: both clouds are sorted along the same curve, so the target at the same
             // relative rank is usually close — any evaluated point is a valid upper bound
             const int g = (int)(((long long)i * m) / n);
             const float2 q = tile[g];
-            best[p] = next_up(dist2(ax[p], ay[p], q.x, q.y));
+            const float ds = dist2(ax[p], ay[p], q.x, q.y);
+            best[p] = F64 ? next_up(reach(ds) * 1.000001f) : next_up(ds);
             bchunk[p] = g / CHUNK;
           }
         }
@@ -257,7 +291,7 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
           const float4 b = aabb[c0 + lane];
           const float dx = fmaxf(fmaxf(b.x - wx1, wx0 - b.z), 0.f);
           const float dy = fmaxf(fmaxf(b.y - wy1, wy0 - b.w), 0.f);
-          cand = wb >= __builtin_fmaf(dy, dy, dx * dx) * kPruneSafety;
+          cand = reach(wb) >= __builtin_fmaf(dy, dy, dx * dx) * kPruneSafety;
         }
         unsigned long long todo = __ballot(cand);
         while (todo) {
@@ -271,7 +305,7 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
           for (int p = 0; p < P; ++p) {
             const float ox = fmaxf(fmaxf(b.x - ax[p], ax[p] - b.z), 0.f);
             const float oy = fmaxf(fmaxf(b.y - ay[p], ay[p] - b.w), 0.f);
-            need_own |= best[p] >= __builtin_fmaf(oy, oy, ox * ox) * kPruneSafety;
+            need_own |= reach(best[p]) >= __builtin_fmaf(oy, oy, ox * ox) * kPruneSafety;
           }
           if (!__any(need_own)) continue;                    // nothing in this chunk can beat or tie any lane
           float4 v[CHUNK / 2];
@@ -297,8 +331,12 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
         }
       }
 
+      bool near[P];                                          // float64-exact mode: another target within the near-tie window of the winner
 #pragma unroll
-      for (int p = 0; p < P; ++p) tie |= (second[p] == best[p]) && (best[p] < INFINITY);
+      for (int p = 0; p < P; ++p) {
+        if constexpr (F64) near[p] = (second[p] <= near_lim(best[p], nt)) && (best[p] < INFINITY);
+        else { near[p] = false; tie |= (second[p] == best[p]) && (best[p] < INFINITY); }
+      }
       // ---- fix-up inside the winning chunk: position of the minimum; equal distances are left to the pass below ----
       int pos[P];
       float bd[P];
@@ -321,10 +359,49 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
           pos[p] = lt ? j0 + k : pos[p];
           bd[p] = lt ? d : bd[p];
         }
-        tie |= (sec2 == bd[p]) && (bd[p] < INFINITY);
+        if constexpr (F64) { near[p] = (near[p] || (sec2 <= near_lim(bd[p], nt) && bd[p] < INFINITY)) && (base + tid * P + p < n); tie |= near[p]; }
+        else tie |= (sec2 == bd[p]) && (bd[p] < INFINITY);
       }
       // ---- equal minima (duplicate or equidistant points, in one chunk or in two): exhaustive pass, lowest ORIGINAL index wins --
-      if (__any(tie)) {
+      if constexpr (F64) {
+        // ---- near ties: every target whose float32 distance is within lim of the winner's is compared in float64
+        // (lowest original index on float64 ties).  Chunks are walked with the flagged lanes' own points and windows.
+        if (__any(tie)) {
+          if (lay.debug_counter && lane == 0) atomicAdd(lay.debug_counter, 1u);
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            if (!__any(near[p])) continue;
+            const int i = base + tid * P + p;
+            const float lim = near[p] ? near_lim(bd[p], nt) : -INFINITY;
+            double adx = 0.0, ady = 0.0;
+            if (near[p]) {
+              const int o = sidx[i];
+              const double x = gsrc64[2 * o], y = gsrc64[2 * o + 1];
+              adx = T[0][0] * x + T[0][1] * y + T[0][3];       // icp.py:116 on the float64 point
+              ady = T[1][0] * x + T[1][1] * y + T[1][3];
+            }
+            double bv = INFINITY;
+            int bo = 0x7fffffff, bp = pos[p];
+            for (int c = 0; c < nchunks; ++c) {
+              const float4 b = aabb[c];
+              const float ox = fmaxf(fmaxf(b.x - ax[p], ax[p] - b.z), 0.f);
+              const float oy = fmaxf(fmaxf(b.y - ay[p], ay[p] - b.w), 0.f);
+              if (!__any(lim >= __builtin_fmaf(oy, oy, ox * ox) * kPruneSafety)) continue;
+              for (int k = 0; k < CHUNK; ++k) {
+                const int j = c * CHUNK + k;
+                const float2 q = tile[j];
+                if (dist2(ax[p], ay[p], q.x, q.y) <= lim) {    // rare: a candidate of this lane (padding is at +inf)
+                  const int o = tidx[j];
+                  const double dx = adx - gtgt64[2 * o], dy = ady - gtgt64[2 * o + 1];
+                  const double e = dx * dx + dy * dy;
+                  if (e < bv || (e == bv && o < bo)) { bv = e; bo = o; bp = j; }
+                }
+              }
+            }
+            if (near[p]) pos[p] = bp;
+          }
+        }
+      } else if (__any(tie)) {
         if (lay.debug_counter && lane == 0) atomicAdd(lay.debug_counter, 1u);
         int oidx[P];
 #pragma unroll
@@ -358,12 +435,19 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
         const int i = base + tid * P + p;
         if (i < n) {
           const int ps = sh_prev[i];
-          const float2 v = src_lds ? sh_src[i] : ssrc[i];
-          const float2 q = tile[ps];
-          double pd[2], qd[2];
-          pd[0] = T[0][0] * (double)v.x + T[0][1] * (double)v.y + T[0][3];
-          pd[1] = T[1][0] * (double)v.x + T[1][1] * (double)v.y + T[1][3];
-          qd[0] = (double)q.x; qd[1] = (double)q.y;
+          double x, y, pd[2], qd[2];
+          if constexpr (F64) {                                // the float64 points themselves (original order)
+            const int so = sidx[i], to = tidx[ps];
+            x = gsrc64[2 * so]; y = gsrc64[2 * so + 1];
+            qd[0] = gtgt64[2 * to]; qd[1] = gtgt64[2 * to + 1];
+          } else {
+            const float2 v = src_lds ? sh_src[i] : ssrc[i];
+            const float2 q = tile[ps];
+            x = (double)v.x; y = (double)v.y;
+            qd[0] = (double)q.x; qd[1] = (double)q.y;
+          }
+          pd[0] = T[0][0] * x + T[0][1] * y + T[0][3];
+          pd[1] = T[1][0] * x + T[1][1] * y + T[1][3];
           acc.add(pd, qd, box);
         }
       }
@@ -472,9 +556,15 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
     hipLaunchKernelGGL(kernel, dim3(S), dim3(threads), smem, stream, a, sc, lay);
     return hipGetLastError();
   };
-  if (P == 1) return launch(icp_pruned_kernel<1>);
-  if (P == 2) return launch(icp_pruned_kernel<2>);
-  return launch(icp_pruned_kernel<4>);
+  if ((a.src64 == nullptr) != (a.tgt64 == nullptr)) return hipErrorInvalidValue;
+  if (a.src64) {
+    if (P == 1) return launch(icp_pruned_kernel<1, true>);
+    if (P == 2) return launch(icp_pruned_kernel<2, true>);
+    return launch(icp_pruned_kernel<4, true>);
+  }
+  if (P == 1) return launch(icp_pruned_kernel<1, false>);
+  if (P == 2) return launch(icp_pruned_kernel<2, false>);
+  return launch(icp_pruned_kernel<4, false>);
 }
 
 }  // namespace lslam

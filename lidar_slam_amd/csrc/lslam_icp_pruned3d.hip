@@ -140,7 +140,8 @@ icp_sort3_kernel(IcpBatchArgs a, PruneScratch3 sc, int len_pow2) {
   }
 }
 
-template <int P>
+// F64: the float64-exact mode (lslam_device.h: NearTie), as in icp_pruned_kernel
+template <int P, bool F64>
 __global__ void __launch_bounds__(kIcpBatchMaxThreads)
 icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
   constexpr int CHUNK = kChunk3;
@@ -166,11 +167,29 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
   const bool box = (args.flags & kFlagNormalize) != 0;
   const int nchunks = (m + CHUNK - 1) / CHUNK;
 
+  const double* __restrict__ gsrc64 = F64 ? args.src64 + 3 * s0 : nullptr;          // original order, like args.src
+  const double* __restrict__ gtgt64 = F64 ? args.tgt64 + 3 * t0 : nullptr;
+  const uint16_t* __restrict__ sidx = sc.src_index + ss;     // original index of a sorted source
   if (tid < 16) sh_T[tid] = args.init_T[(int64_t)16 * pair + tid];
-  for (int j = tid; j < nchunks * CHUNK; j += blockDim.x) tile[j] = (j < m) ? sc.tgt_sorted[ts + j] : make_float4(kFar, kFar, kFar, 0.f);
+  if (F64 && tid == 0) { sh_flag[1] = 0; sh_flag[2] = 0; }   // bits of max |t|², max |p|²
+  float tmax = 0.f, smax = 0.f;
+  for (int j = tid; j < nchunks * CHUNK; j += blockDim.x) {
+    const float4 v = (j < m) ? sc.tgt_sorted[ts + j] : make_float4(kFar, kFar, kFar, 0.f);
+    tile[j] = v;
+    if (F64 && j < m) tmax = fmaxf(tmax, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
+  }
   const bool src_lds = lay.src_off != 0xffffffffu;
-  for (int i = tid; i < n; i += blockDim.x) { if (src_lds) sh_src[i] = ssrc[i]; sh_prev[i] = 0xffff; }
+  for (int i = tid; i < n; i += blockDim.x) {
+    const float4 v = ssrc[i];
+    if (src_lds) sh_src[i] = v;
+    sh_prev[i] = 0xffff;
+    if (F64) smax = fmaxf(smax, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
+  }
   __syncthreads();
+  if constexpr (F64) {
+    tmax = wmax3(tmax); smax = wmax3(smax);
+    if (lane == 0) { atomicMax(&sh_flag[1], __float_as_int(tmax)); atomicMax(&sh_flag[2], __float_as_int(smax)); }
+  }
   for (int c = tid; c < nchunks; c += blockDim.x) {          // boxes over the real points only
     float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
     for (int k = 0; k < CHUNK && c * CHUNK + k < m; ++k) {
@@ -182,6 +201,11 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
   }
   if (tid == 0) { StopState st0; stop_init(st0); *sh_stop = st0; *sh_err = 0.0; }
   __syncthreads();
+  float Rt = 0.f, Rs = 0.f;
+  if constexpr (F64) {
+    Rt = sqrtf(__int_as_float(sh_flag[1])) * 1.0001f;
+    Rs = sqrtf(__int_as_float(sh_flag[2])) * 1.0001f;
+  }
   const int per_pass = blockDim.x * P;
   const int passes = n > 0 ? (n + per_pass - 1) / per_pass : 1;
 
@@ -199,6 +223,17 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) T[r][c] = wave_uniform(sh_T[4 * r + c]);
+    NearTie nt = near_tie_setup(false, 0.f, 0.f, 0.f);
+    if constexpr (F64) {
+      double f2 = 0.0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f2 += T[r][c] * T[r][c];
+      nt = near_tie_setup(true, Rt, Rs, sqrtf((float)f2) * 1.0001f);
+    }
+    // the bound a chunk must beat: the lane's best itself, or in float64-exact mode everything within its near-tie window
+    auto reach = [&](float b) { return F64 ? __builtin_fmaf(b, nt.K1, nt.C) : b; };
 
     // ---- phase A: nearest neighbours (float32); the matches go to LDS (they also seed the next iteration)
     for (int pass = 0; pass < passes; ++pass) {
@@ -236,7 +271,9 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
           int pv = sh_prev[i];
           if (pv == 0xffff) pv = (int)(((long long)i * m) / n);
           const float4 q = tile[pv];
-          best[p] = next_up3(dist2(a[p][0], a[p][1], a[p][2], q.x, q.y, q.z));   // a bound, not yet a candidate: its chunk will beat it strictly
+          // a bound, not yet a candidate: its chunk will beat it strictly (float64-exact mode: by more than the near-tie window)
+          const float ds = dist2(a[p][0], a[p][1], a[p][2], q.x, q.y, q.z);
+          best[p] = F64 ? next_up3(reach(ds) * 1.000001f) : next_up3(ds);
           bchunk[p] = pv / CHUNK;
         }
       }
@@ -249,7 +286,7 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
       wb = wmax3(wb);
       for (int c0 = 0; c0 < nchunks; c0 += 64) {
         bool cand = false;
-        if (c0 + lane < nchunks) cand = wb >= box_dist(wlo, whi, aabb[2 * (c0 + lane)], aabb[2 * (c0 + lane) + 1]);
+        if (c0 + lane < nchunks) cand = reach(wb) >= box_dist(wlo, whi, aabb[2 * (c0 + lane)], aabb[2 * (c0 + lane) + 1]);
         unsigned long long todo = __ballot(cand);
         while (todo) {
           const int c = c0 + __builtin_ctzll(todo);
@@ -257,7 +294,7 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
           const float4 blo = aabb[2 * c], bhi = aabb[2 * c + 1];
           bool need_own = false;
 #pragma unroll
-          for (int p = 0; p < P; ++p) need_own |= best[p] >= box_dist(a[p], a[p], blo, bhi);
+          for (int p = 0; p < P; ++p) need_own |= reach(best[p]) >= box_dist(a[p], a[p], blo, bhi);
           if (!__any(need_own)) continue;                    // nothing in this chunk can beat or tie any lane
 #pragma unroll
           for (int p = 0; p < P; ++p) {
@@ -274,8 +311,12 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
           }
         }
       }
+      bool near[P];                                          // float64-exact mode: another target within the near-tie window of the winner
 #pragma unroll
-      for (int p = 0; p < P; ++p) tie |= (second[p] == best[p]) && (best[p] < INFINITY);
+      for (int p = 0; p < P; ++p) {
+        if constexpr (F64) near[p] = (second[p] <= near_lim(best[p], nt)) && (best[p] < INFINITY);
+        else { near[p] = false; tie |= (second[p] == best[p]) && (best[p] < INFINITY); }
+      }
 
       // ---- fix-up inside the winning chunk: position of the minimum; equal distances are left to the pass below ----
       int pos[P];
@@ -297,10 +338,46 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
           pos[p] = lt ? j0 + k : pos[p];
           bd[p] = lt ? d : bd[p];
         }
-        tie |= (sec2 == bd[p]) && (bd[p] < INFINITY);
+        if constexpr (F64) { near[p] = (near[p] || (sec2 <= near_lim(bd[p], nt) && bd[p] < INFINITY)) && (base + tid * P + p < n); tie |= near[p]; }
+        else tie |= (sec2 == bd[p]) && (bd[p] < INFINITY);
       }
       // ---- equal minima (duplicate or equidistant points): exhaustive pass, lowest ORIGINAL index wins --
-      if (__any(tie)) {
+      if constexpr (F64) {
+        // ---- near ties: every target whose float32 distance is within lim of the winner's is compared in float64
+        // (lowest original index on float64 ties); chunks are walked with the flagged lanes' own points and windows
+        if (__any(tie)) {
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            if (!__any(near[p])) continue;
+            const int i = base + tid * P + p;
+            const float lim = near[p] ? near_lim(bd[p], nt) : -INFINITY;
+            double ad[3] = {0.0, 0.0, 0.0};
+            if (near[p]) {
+              const int o = sidx[i];
+              const double x = gsrc64[3 * o], y = gsrc64[3 * o + 1], z = gsrc64[3 * o + 2];
+#pragma unroll
+              for (int r = 0; r < 3; ++r) ad[r] = T[r][0] * x + T[r][1] * y + T[r][2] * z + T[r][3];      // icp.py:116 on the float64 point
+            }
+            double bv = INFINITY;
+            int bo = 0x7fffffff, bp = pos[p];
+            for (int c = 0; c < nchunks; ++c) {
+              if (!__any(lim >= box_dist(a[p], a[p], aabb[2 * c], aabb[2 * c + 1]))) continue;
+              for (int k = 0; k < CHUNK; ++k) {
+                const int j = c * CHUNK + k;
+                const float4 q = tile[j];
+                if (dist2(a[p][0], a[p][1], a[p][2], q.x, q.y, q.z) <= lim) {      // rare: a candidate of this lane (padding is at +inf)
+                  const int o = tidx[j];
+                  double e = 0.0;
+#pragma unroll
+                  for (int r = 0; r < 3; ++r) { const double df = ad[r] - gtgt64[3 * o + r]; e += df * df; }
+                  if (e < bv || (e == bv && o < bo)) { bv = e; bo = o; bp = j; }
+                }
+              }
+            }
+            if (near[p]) pos[p] = bp;
+          }
+        }
+      } else if (__any(tie)) {
         int oidx[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) { bd[p] = INFINITY; oidx[p] = 0x7fffffff; }
@@ -330,12 +407,19 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
       for (int p = 0; p < P; ++p) {
         const int i = base + tid * P + p;
         if (i < n) {
-          const float4 v = src_lds ? sh_src[i] : ssrc[i];
-          const float4 q = tile[sh_prev[i]];
-          double pd[3], qd[3];
+          double x, y, z, pd[3], qd[3];
+          if constexpr (F64) {                                // the float64 points themselves (original order)
+            const int so = sidx[i], to = tidx[sh_prev[i]];
+            x = gsrc64[3 * so]; y = gsrc64[3 * so + 1]; z = gsrc64[3 * so + 2];
+            qd[0] = gtgt64[3 * to]; qd[1] = gtgt64[3 * to + 1]; qd[2] = gtgt64[3 * to + 2];
+          } else {
+            const float4 v = src_lds ? sh_src[i] : ssrc[i];
+            const float4 q = tile[sh_prev[i]];
+            x = (double)v.x; y = (double)v.y; z = (double)v.z;
+            qd[0] = (double)q.x; qd[1] = (double)q.y; qd[2] = (double)q.z;
+          }
 #pragma unroll
-          for (int r = 0; r < 3; ++r) pd[r] = T[r][0] * (double)v.x + T[r][1] * (double)v.y + T[r][2] * (double)v.z + T[r][3];
-          qd[0] = (double)q.x; qd[1] = (double)q.y; qd[2] = (double)q.z;
+          for (int r = 0; r < 3; ++r) pd[r] = T[r][0] * x + T[r][1] * y + T[r][2] * z + T[r][3];
           acc.add(pd, qd, box);
         }
       }
@@ -428,8 +512,9 @@ hipError_t launch_icp_pruned3(IcpBatchArgs a, const PruneScratch3& sc, int S, in
     hipLaunchKernelGGL(kernel, dim3(S), dim3(threads), smem, stream, a, sc, lay);
     return hipGetLastError();
   };
-  if (P == 2) return launch(icp_pruned3_kernel<2>);
-  return launch(icp_pruned3_kernel<1>);
+  if ((a.src64 == nullptr) != (a.tgt64 == nullptr)) return hipErrorInvalidValue;
+  if (a.src64) return P == 2 ? launch(icp_pruned3_kernel<2, true>) : launch(icp_pruned3_kernel<1, true>);
+  return P == 2 ? launch(icp_pruned3_kernel<2, false>) : launch(icp_pruned3_kernel<1, false>);
 }
 
 }  // namespace lslam

@@ -44,6 +44,11 @@ struct IcpBatchArgs {
   uint32_t src_bytes;        // filled by the launcher: LDS reserved for the source cloud (0 = read it from memory)
   uint32_t w_bytes;          // filled by the launcher: LDS reserved for |t|² per target (planar filter build, else 0)
   unsigned* debug;           // LSLAM_DEBUG: [0] filter passes attempted, [1] passes that fell back to the exact sweep (or nullptr)
+  // float64-exact mode (both set, or both nullptr): the same clouds in float64, laid out like src / tgt.  The float32
+  // search then only proposes candidates; near ties are decided, and the moments accumulated, on these points — the
+  // correspondences are those of a float64 search (modules/icp.py:29-41), lowest index on exact float64 ties.
+  const double* src64;
+  const double* tgt64;
 };
 
 struct IcpBatchTuning {
