@@ -17,8 +17,10 @@ def test_packed_scans_is_a_list_of_views_and_packs_without_copying_element_by_el
     z = _scans(rng, [5, 0, 7, 3])
     assert isinstance(z, list) and len(z) == 4 and [s.shape for s in z] == [(5, 2), (0, 2), (7, 2), (3, 2)]
     flat, off = pack_clouds(z)
-    assert flat.dtype == np.float32 and off is z.off
-    np.testing.assert_array_equal(flat, z.flat.astype(np.float32))
+    assert flat.dtype == np.float64 and off is z.off and flat is z.flat        # float64-exact mode: the packed array itself, no copy
+    f32, off32 = pack_clouds(z, dtype=np.float32)
+    assert f32.dtype == np.float32 and off32 is z.off
+    np.testing.assert_array_equal(f32, z.flat.astype(np.float32))
     # writing INTO an element writes into the packed array (elements are views)
     z[2][:] = 1.5
     flat2, _ = pack_clouds(z)
@@ -44,8 +46,9 @@ def test_mutating_the_list_is_honoured_like_a_plain_list():
         edit(z)
         assert z.packed() is None, name
         flat, off = pack_clouds(z)                                   # re-packed from the list as it is now
-        want = np.concatenate([np.asarray(s) for s in z], axis=0).astype(np.float32)
+        want = np.concatenate([np.asarray(s) for s in z], axis=0)
         np.testing.assert_array_equal(flat, want, err_msg=name)
+        np.testing.assert_array_equal(pack_clouds(z, dtype=np.float32)[0], want.astype(np.float32), err_msg=name)
         assert off.tolist() == np.concatenate(([0], np.cumsum([s.shape[0] for s in z]))).tolist(), name
 
 
