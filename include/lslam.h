@@ -157,6 +157,20 @@ int lslam_icp_large_dev(const float *d_src, int64_t n, const float *d_tgt, int64
                         double *out_T, double *out_err, int32_t *out_iters,
                         int32_t *d_out_corr, void *stream);
 
+/* float64-exact mode of the two entry points above (see lslam_icp_batch_f64): the float64 clouds decide near
+ * ties and feed the moments.  Pruning is not available in this mode (the flag is ignored: all pairs). */
+int lslam_icp_large_f64(const double *src, int64_t n, const double *tgt, int64_t m, int dim,
+                        const double *init_T, double epsilon, double stopping_thresh,
+                        int32_t max_iters, uint32_t flags,
+                        double *out_T, double *out_err, int32_t *out_iters,
+                        int32_t *out_corr, int device);
+int lslam_icp_large_dev64(const float *d_src, const double *d_src64, int64_t n,
+                          const float *d_tgt, const double *d_tgt64, int64_t m, int dim,
+                          const double *init_T, double epsilon, double stopping_thresh,
+                          int32_t max_iters, uint32_t flags, int32_t poll_every,
+                          double *out_T, double *out_err, int32_t *out_iters,
+                          int32_t *d_out_corr, void *stream);
+
 /* Same with HOST clouds (float32, validated: finite, non-empty target) and HOST out_corr
  * (n int32 or NULL); copies through library-owned device scratch. */
 int lslam_icp_large(const float *src, int64_t n, const float *tgt, int64_t m,

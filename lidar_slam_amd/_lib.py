@@ -55,6 +55,12 @@ SIGNATURES = {
     "lslam_icp_large_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                       C.c_double, C.c_double, C.c_int32, C.c_uint32, C.c_int32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lslam_icp_large_dev64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                        C.c_double, C.c_double, C.c_int32, C.c_uint32, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lslam_icp_large_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_double,
+                                      C.c_double, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int]),
     "lslam_icp_large": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_double,
                                   C.c_double, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int]),

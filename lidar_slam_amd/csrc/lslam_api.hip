@@ -388,6 +388,34 @@ struct LargeWs {
   LargeState* h_state = nullptr;       // pinned
   LargeState* h_back[2] = {nullptr, nullptr};   // pinned read-back slots of alternating polls
   hipEvent_t polled[2] = {nullptr, nullptr};
+  float* sec = nullptr; int64_t sec_cap = 0;                  // float64-exact mode: second smallest distance per (split, source)
+  float* bounds = nullptr;                                    // {max |t|², max |p|²}
+  int ensure_sec(int64_t count) {
+    if (!bounds) LSLAM_HIP_TRY(hipMalloc(&bounds, 16));
+    if (count > sec_cap) {
+      if (sec) { LSLAM_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(sec); }
+      sec = nullptr; sec_cap = 0;
+      LSLAM_HIP_TRY(hipMalloc(&sec, sizeof(float) * (size_t)count));
+      sec_cap = count;
+    }
+    return LSLAM_OK;
+  }
+  unsigned long long* gran = nullptr; size_t gran_cap = 0;   // moment rows of the co-resident workgroups (lslam_icp_coop.hip)
+  unsigned* coop_failed = nullptr;                            // device word
+  unsigned* h_failed = nullptr;                               // pinned
+  int ensure_coop(size_t bytes) {
+    if (!coop_failed) {
+      LSLAM_HIP_TRY(hipMalloc(&coop_failed, 128));
+      LSLAM_HIP_TRY(hipHostMalloc(&h_failed, 128));
+    }
+    if (bytes > gran_cap) {
+      if (gran) { LSLAM_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(gran); }
+      gran = nullptr; gran_cap = 0;
+      LSLAM_HIP_TRY(hipMalloc(&gran, bytes));
+      gran_cap = bytes;
+    }
+    return LSLAM_OK;
+  }
   int ensure(int dev, int64_t n) {
     if (dev != device) { release(); device = dev; }
     if (!partials) {
@@ -412,6 +440,13 @@ struct LargeWs {
     if (partials) (void)hipFree(partials);
     if (state) (void)hipFree(state);
     if (h_state) (void)hipHostFree(h_state);
+    if (gran) (void)hipFree(gran);
+    if (sec) (void)hipFree(sec);
+    if (bounds) (void)hipFree(bounds);
+    sec = nullptr; sec_cap = 0; bounds = nullptr;
+    if (coop_failed) (void)hipFree(coop_failed);
+    if (h_failed) (void)hipHostFree(h_failed);
+    gran = nullptr; gran_cap = 0; coop_failed = nullptr; h_failed = nullptr;
     for (int i = 0; i < 2; ++i) {
       if (h_back[i]) (void)hipHostFree(h_back[i]);
       if (polled[i]) (void)hipEventDestroy(polled[i]);
@@ -461,7 +496,7 @@ LpHolder& lp_holder() { static thread_local LpHolder h; return h; }
 }  // namespace
 }  // extern "C++"
 
-static int icp_large_dev_impl(const float* d_src, int64_t n, const float* d_tgt, int64_t m, int dim,
+static int icp_large_dev_impl(const float* d_src, const double* d_src64, int64_t n, const float* d_tgt, const double* d_tgt64, int64_t m, int dim,
                               const double* init_T, double epsilon, double stopping_thresh, int32_t max_iters,
                               uint32_t flags, int32_t poll_every, double* out_T, double* out_err,
                               int32_t* out_iters, int32_t* d_out_corr, void* stream) {
@@ -470,15 +505,55 @@ static int icp_large_dev_impl(const float* d_src, int64_t n, const float* d_tgt,
   if (n <= 0) return fail(LSLAM_ERR_BAD_ARG, "empty source cloud");
   if (m <= 0) return fail(LSLAM_ERR_EMPTY_TARGET, "empty target cloud");
   if (n > 0x7fffffff || m > 0x7fffffff) return fail(LSLAM_ERR_BAD_ARG, "clouds above 2^31 points are not supported");
+  if ((d_src64 == nullptr) != (d_tgt64 == nullptr)) return fail(LSLAM_ERR_BAD_ARG, "float64 clouds: pass both or neither");
+  const bool f64 = d_src64 != nullptr;
   if (poll_every <= 0) poll_every = 8;
   int dev = 0;
   LSLAM_HIP_TRY(hipGetDevice(&dev));
   LargeWs& ws = large_ws();
-  const bool prune = want_pruning(flags, (double)n * (double)m >= (dim == 2 ? kAutoPruneLargePairEvals2D : kAutoPruneLargePairEvals3D));
+  // float64-exact mode: the pruned whole-chip search has no float64 refinement — all pairs there
+  const bool prune = !f64 && want_pruning(flags, (double)n * (double)m >= (dim == 2 ? kAutoPruneLargePairEvals2D : kAutoPruneLargePairEvals3D));
   const NnGeometry geo = nn_geometry(dim, n, m);
   int rc = ws.ensure(dev, prune ? 1 : n * geo.splits);
   if (rc != LSLAM_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
+
+  // ---- LiDAR-sized pair: the whole run inside ONE launch of co-resident workgroups (lslam_icp_coop.hip) -------------
+  if (!prune && icp_coop_supported(dim, n, m, f64)) {
+    if ((rc = ws.ensure_coop(icp_coop_gran_bytes(dim, n))) != LSLAM_OK) return rc;
+    LargeState* hs0 = ws.h_state;
+    memcpy(hs0->T, init_T, sizeof(double) * 16);
+    hs0->err = 0.0;
+    stop_init(hs0->stop);
+    hs0->done = 0;
+    hs0->ticket = 0;
+    LSLAM_HIP_TRY(hipMemcpyAsync(ws.state, hs0, sizeof(LargeState), hipMemcpyHostToDevice, st));
+    LSLAM_HIP_TRY(hipMemsetAsync(ws.coop_failed, 0, 16, st));
+    CoopArgs ca{};
+    ca.src = d_src; ca.n = (int32_t)n; ca.tgt = d_tgt; ca.m = (int32_t)m; ca.src64 = d_src64; ca.tgt64 = d_tgt64;
+    ca.state = ws.state; ca.gran = ws.gran; ca.failed = ws.coop_failed; ca.out_corr = d_out_corr; ca.flags = flags;
+    ca.epsilon = epsilon; ca.stopping_thresh = stopping_thresh; ca.max_iters = max_iters;
+    LSLAM_HIP_TRY(launch_icp_coop(ca, dim, st));
+    LSLAM_HIP_TRY(hipMemcpyAsync(ws.h_back[0], ws.state, sizeof(LargeState), hipMemcpyDeviceToHost, st));
+    LSLAM_HIP_TRY(hipMemcpyAsync(ws.h_failed, ws.coop_failed, 128, hipMemcpyDeviceToHost, st));
+    LSLAM_HIP_TRY(hipStreamSynchronize(st));
+#ifdef LSLAM_COOP_PROFILE
+    {
+      const unsigned long long* pr = reinterpret_cast<const unsigned long long*>(ws.h_failed + 8);
+      fprintf(stderr, "[lslam] coop phases (us, workgroup 0 thread 0, %d iterations): sweep %.2f  barrierA %.2f  slices+refine %.2f  moments %.2f  publish %.2f  gather %.2f  solve %.2f  barrierD %.2f\n",
+              ws.h_back[0]->stop.executed, pr[0] * 0.01, pr[1] * 0.01, pr[2] * 0.01, pr[3] * 0.01, pr[4] * 0.01, pr[5] * 0.01, pr[6] * 0.01, pr[7] * 0.01);
+    }
+#endif
+    if (ws.h_failed[0]) return fail(LSLAM_ERR_HIP, "co-resident ICP launch: a workgroup timed out waiting for the others");
+    memcpy(out_T, ws.h_back[0]->T, sizeof(double) * 16);
+    *out_err = ws.h_back[0]->err;
+    *out_iters = ws.h_back[0]->stop.executed;
+    return LSLAM_OK;
+  }
+  if (f64) {                                                // three launches per iteration, the moments kernel decides the near ties
+    if ((rc = ws.ensure_sec(n * geo.splits)) != LSLAM_OK) return rc;
+    LSLAM_HIP_TRY(launch_cloud_bounds(d_src, n, d_tgt, m, dim, ws.bounds, st));
+  }
   LpWs lp{};
   LpTree tree{};
   if (prune) {
@@ -496,7 +571,8 @@ static int icp_large_dev_impl(const float* d_src, int64_t n, const float* d_tgt,
 
   NnArgs na{};
   na.src = d_src; na.n = n; na.tgt = d_tgt; na.m = m; na.keys = ws.keys; na.state = ws.state;
-  bool fuse = !prune && geo.P == 1;                         // small problem: one launch per iteration
+  bool fuse = !prune && !f64 && geo.P == 1;                 // small problem: one launch per iteration
+  if (f64) { na.sec = ws.sec; na.bounds = ws.bounds; }
   if (const char* e = getenv("LSLAM_ICP_FUSE_TAIL")) fuse = fuse && atoi(e) != 0;
   if (fuse) {
     na.fuse_state = ws.state; na.out_corr = d_out_corr; na.splits = geo.splits; na.flags = flags;
@@ -506,6 +582,7 @@ static int icp_large_dev_impl(const float* d_src, int64_t n, const float* d_tgt,
   MomArgs ma{};
   ma.src = d_src; ma.n = n; ma.tgt = d_tgt; ma.keys = ws.keys; ma.splits = geo.splits; ma.state = ws.state; ma.partials = ws.partials;
   ma.out_corr = d_out_corr; ma.flags = flags;
+  if (f64) { ma.src64 = d_src64; ma.tgt64 = d_tgt64; ma.m = m; ma.sec = ws.sec; ma.bounds = ws.bounds; }
   const int rows = moments_rows(n);
   SolveArgs sa{};
   sa.state = ws.state; sa.partials = ws.partials; sa.rows = rows; sa.flags = flags;
@@ -564,17 +641,25 @@ static int icp_large_dev_impl(const float* d_src, int64_t n, const float* d_tgt,
   return LSLAM_OK;
 }
 
+int lslam_icp_large_dev64(const float* d_src, const double* d_src64, int64_t n, const float* d_tgt, const double* d_tgt64, int64_t m, int dim,
+                          const double* init_T, double epsilon, double stopping_thresh, int32_t max_iters,
+                          uint32_t flags, int32_t poll_every, double* out_T, double* out_err,
+                          int32_t* out_iters, int32_t* d_out_corr, void* stream) {
+  clear_error();
+  int rc = ws_fence().enter(static_cast<hipStream_t>(stream));
+  if (rc != LSLAM_OK) return rc;
+  rc = icp_large_dev_impl(d_src, d_src64, n, d_tgt, d_tgt64, m, dim, init_T, epsilon, stopping_thresh, max_iters, flags, poll_every,
+                          out_T, out_err, out_iters, d_out_corr, stream);
+  const int rc2 = ws_fence().leave(static_cast<hipStream_t>(stream));
+  return rc != LSLAM_OK ? rc : rc2;
+}
+
 int lslam_icp_large_dev(const float* d_src, int64_t n, const float* d_tgt, int64_t m, int dim,
                         const double* init_T, double epsilon, double stopping_thresh, int32_t max_iters,
                         uint32_t flags, int32_t poll_every, double* out_T, double* out_err,
                         int32_t* out_iters, int32_t* d_out_corr, void* stream) {
-  clear_error();
-  int rc = ws_fence().enter(static_cast<hipStream_t>(stream));
-  if (rc != LSLAM_OK) return rc;
-  rc = icp_large_dev_impl(d_src, n, d_tgt, m, dim, init_T, epsilon, stopping_thresh, max_iters, flags, poll_every,
-                          out_T, out_err, out_iters, d_out_corr, stream);
-  const int rc2 = ws_fence().leave(static_cast<hipStream_t>(stream));
-  return rc != LSLAM_OK ? rc : rc2;
+  return lslam_icp_large_dev64(d_src, nullptr, n, d_tgt, nullptr, m, dim, init_T, epsilon, stopping_thresh, max_iters, flags,
+                               poll_every, out_T, out_err, out_iters, d_out_corr, stream);
 }
 
 static int nn_dev_impl(const float* d_src, int64_t n, const float* d_tgt, int64_t m, int dim, const double* T,
@@ -646,6 +731,43 @@ int lslam_icp_large(const float* src, int64_t n, const float* tgt, int64_t m, in
   if (rc != LSLAM_OK) return rc;
   if (out_corr) {
     LSLAM_HIP_TRY(hipMemcpyAsync(out_corr, d_corr, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+    LSLAM_HIP_TRY(hipStreamSynchronize(st));
+  }
+  return LSLAM_OK;
+}
+
+int lslam_icp_large_f64(const double* src, int64_t n, const double* tgt, int64_t m, int dim, const double* init_T,
+                        double epsilon, double stopping_thresh, int32_t max_iters, uint32_t flags,
+                        double* out_T, double* out_err, int32_t* out_iters, int32_t* out_corr, int device) {
+  clear_error();
+  if (dim != 2 && dim != 3) return fail(LSLAM_ERR_BAD_ARG, "dim must be 2 or 3, got %d", dim);
+  if (!src || !tgt) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (n <= 0) return fail(LSLAM_ERR_BAD_ARG, "empty source cloud");
+  if (m <= 0) return fail(LSLAM_ERR_EMPTY_TARGET, "empty target cloud");
+  if (!all_finite64(src, dim * n) || !all_finite64(tgt, dim * m))
+    return fail(LSLAM_ERR_NONFINITE, "point clouds must be finite (NaN or Inf found)");
+  int rc;
+  if ((rc = use_device(device)) != LSLAM_OK) return rc;
+  Arena& ar = thread_arena();
+  const size_t cs = (size_t)dim * (size_t)n, ct = (size_t)dim * (size_t)m;
+  const size_t b_corr = out_corr ? sizeof(int32_t) * (size_t)n : 0;
+  if ((rc = ar.reserve(device, Arena::align(4 * cs) + Arena::align(4 * ct) + Arena::align(8 * cs) + Arena::align(8 * ct) + Arena::align(b_corr))) != LSLAM_OK) return rc;
+  float* d_src = static_cast<float*>(ar.carve(4 * cs));
+  float* d_tgt = static_cast<float*>(ar.carve(4 * ct));
+  double* d_src64 = static_cast<double*>(ar.carve(8 * cs));
+  double* d_tgt64 = static_cast<double*>(ar.carve(8 * ct));
+  int32_t* d_corr = out_corr ? static_cast<int32_t*>(ar.carve(b_corr)) : nullptr;
+  hipStream_t st;
+  if ((rc = thread_stream(&st)) != LSLAM_OK) return rc;
+  LSLAM_HIP_TRY(hipMemcpyAsync(d_src64, src, 8 * cs, hipMemcpyHostToDevice, st));
+  LSLAM_HIP_TRY(hipMemcpyAsync(d_tgt64, tgt, 8 * ct, hipMemcpyHostToDevice, st));
+  LSLAM_HIP_TRY(launch_f64_to_f32(d_src64, d_src, (int64_t)cs, st));
+  LSLAM_HIP_TRY(launch_f64_to_f32(d_tgt64, d_tgt, (int64_t)ct, st));
+  rc = lslam_icp_large_dev64(d_src, d_src64, n, d_tgt, d_tgt64, m, dim, init_T, epsilon, stopping_thresh, max_iters, flags, 8,
+                             out_T, out_err, out_iters, d_corr, st);
+  if (rc != LSLAM_OK) return rc;
+  if (out_corr) {
+    LSLAM_HIP_TRY(hipMemcpyAsync(out_corr, d_corr, b_corr, hipMemcpyDeviceToHost, st));
     LSLAM_HIP_TRY(hipStreamSynchronize(st));
   }
   return LSLAM_OK;

@@ -49,6 +49,33 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 
+// Element `lane & 15` (row-major) of T_step·T_prev, with T_step = [R | qb − R·pb] built from the moments — the SAME
+// operations in the same order as step_from_moments + matmul4 perform for that element (bit-identical), but spread
+// over 16 lanes: the one-lane version is a chain of ≈ 150 dependent float64 operations in every ICP iteration of every
+// kernel.  All lanes of the wave hold the same R, pb, qb; `scratch` = 16 doubles of LDS nobody else touches; sh_Tprev =
+// the current transform in LDS (read here; the caller stores the result back after this call returns).
+__device__ __forceinline__ double step_times_prev_lane(const double (&R)[9], const double (&pb)[3], const double (&qb)[3],
+                                                       const double* sh_Tprev, double* scratch, int lane) {
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) scratch[k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { scratch[9 + k] = pb[k]; scratch[12 + k] = qb[k]; }
+  }
+  const int i = (lane >> 2) & 3, j = lane & 3;
+  double ts0 = 0.0, ts1 = 0.0, ts2 = 0.0, ts3 = 1.0;           // row i of T_step (row 3: 0 0 0 1)
+  if (i < 3) {
+    ts0 = scratch[3 * i]; ts1 = scratch[3 * i + 1]; ts2 = scratch[3 * i + 2];
+    ts3 = scratch[12 + i] - (ts0 * scratch[9] + ts1 * scratch[10] + ts2 * scratch[11]);
+  }
+  double s = 0.0;                                               // matmul4's accumulation order
+  s += ts0 * sh_Tprev[j];
+  s += ts1 * sh_Tprev[4 + j];
+  s += ts2 * sh_Tprev[8 + j];
+  s += ts3 * sh_Tprev[12 + j];
+  return s;
+}
+
 // ---- the expanded-form FILTER of the all-pairs sweeps -----------------------
 //   g(a, t) = |t|² − 2 a·t  ( = |a − t|² − |a|² )      2 (planar) / 3 (3-D) v_fma per pair, |t|² kept beside the target
 // g is only a filter: its float32 error against the exact direct-difference distance is bounded, so the exact

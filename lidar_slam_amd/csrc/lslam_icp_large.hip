@@ -40,7 +40,8 @@ __device__ __forceinline__ unsigned long long reduce_keys(const unsigned long lo
   return k;
 }
 
-template <int DIM, int P, bool FUSE>
+// SEC (float64-exact mode): also the second smallest distance of the split, one float per (split, source) in a.sec
+template <int DIM, int P, bool FUSE, bool SEC = false>
 __global__ void __launch_bounds__(kNnThreads)
 nn_tiled_kernel(NnArgs a) {
   constexpr int CHUNK = NnChunk<DIM>::value;
@@ -82,10 +83,10 @@ nn_tiled_kernel(NnArgs a) {
   const int64_t c_begin = (int64_t)blockIdx.y * a.chunks_per_split;      // whole tiles per split
   const int64_t c_end = min(chunks_total, c_begin + a.chunks_per_split);
 
-  float best[P];
+  float best[P], second[P];
   int bchunk[P];
 #pragma unroll
-  for (int p = 0; p < P; ++p) { best[p] = INFINITY; bchunk[p] = (int)c_begin; }
+  for (int p = 0; p < P; ++p) { best[p] = INFINITY; second[p] = INFINITY; bchunk[p] = (int)c_begin; }
 
   const int tile_chunks = a.tile_points / CHUNK;
   for (int64_t c0 = c_begin; c0 < c_end; c0 += tile_chunks) {
@@ -123,6 +124,7 @@ nn_tiled_kernel(NnArgs a) {
             mn = fminf(fminf(d0, d1), mn);
           }
           const bool lt = mn < best[p];
+          if constexpr (SEC) second[p] = __builtin_amdgcn_fmed3f(best[p], second[p], mn);
           bchunk[p] = lt ? (int)(c0 + c) : bchunk[p];
           best[p] = lt ? mn : best[p];
         }
@@ -143,6 +145,7 @@ nn_tiled_kernel(NnArgs a) {
           }
           mn = fminf(mn, dist2(s[p][0], s[p][1], s[p][2], v[CHUNK - 1].x, v[CHUNK - 1].y, v[CHUNK - 1].z));
           const bool lt = mn < best[p];
+          if constexpr (SEC) second[p] = __builtin_amdgcn_fmed3f(best[p], second[p], mn);
           bchunk[p] = lt ? (int)(c0 + c) : bchunk[p];
           best[p] = lt ? mn : best[p];
         }
@@ -157,10 +160,11 @@ nn_tiled_kernel(NnArgs a) {
     if (i >= a.n) continue;
     if (c_begin >= c_end) {                                  // empty split: neutral key
       if constexpr (!FUSE) keys[i] = kKeyInit;
+      if constexpr (SEC) a.sec[(int64_t)blockIdx.y * a.n + i] = INFINITY;
       continue;
     }
     const int64_t j0 = (int64_t)bchunk[p] * CHUNK;
-    float bd = INFINITY;
+    float bd = INFINITY, sec2 = INFINITY;
     int64_t bi = j0;
 #pragma unroll
     for (int k = 0; k < CHUNK; ++k) {
@@ -175,8 +179,10 @@ nn_tiled_kernel(NnArgs a) {
         const float bz = in ? a.tgt[DIM * j + 2] : kFar;
         d = dist2(s[p][0], s[p][1], s[p][2], bx, by, bz);
       }
+      if constexpr (SEC) sec2 = __builtin_amdgcn_fmed3f(bd, sec2, d);
       if (d < bd || k == 0) { bd = d; bi = j; }
     }
+    if constexpr (SEC) a.sec[(int64_t)blockIdx.y * a.n + i] = fminf(second[p], sec2);
     const unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(uint32_t)bi;
     if constexpr (FUSE) atomicMin(&a.keys[i], key);         // one key row shared by the splits (reset by the tail)
     else keys[i] = key;
@@ -262,7 +268,7 @@ nn_tiled_kernel(NnArgs a) {
 // from global memory cost as much as the sweep: 12-byte points, one cache line per lane and load); a wave in which a
 // third chunk is within τ re-sweeps the tile with the exact recipe (rare: a split holds 1/splits of the target's
 // density).  The key written is the same exact (d² bits, index) as nn_tiled_kernel writes.
-template <int DIM, int P>
+template <int DIM, int P, bool SEC = false>
 __global__ void __launch_bounds__(kNnThreads)
 nn_tiled_filter_kernel(NnArgs a) {
   constexpr int CHUNK = NnChunk<DIM>::value, FCH = kFilterChunk;
@@ -351,6 +357,17 @@ nn_tiled_filter_kernel(NnArgs a) {
   __syncthreads();                                            // every wave's maximum is in
   const float Rt = sqrtf(__int_as_float(sh_wmax)) * 1.0001f;
 
+  // float64-exact mode: the chunks kept must hold every target within the near-tie window of the winner (filter_decide widens τ);
+  // the window needs bounds on |t| (this split's Rt ≤ the cloud's) and |p| (the cloud's, from a.bounds) and T's norm
+  NearTie nt = near_tie_setup(false, 0.f, 0.f, 0.f);
+  if constexpr (SEC) {
+    double f2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < DIM; ++r)
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) f2 += T[r][c] * T[r][c];
+    nt = near_tie_setup(true, sqrtf(a.bounds[0]) * 1.0001f, sqrtf(a.bounds[1]) * 1.0001f, sqrtf((float)f2) * 1.0001f);
+  }
   float s[P][DIM];
   bool two[P], fall = false;
 #pragma unroll
@@ -358,40 +375,44 @@ nn_tiled_filter_kernel(NnArgs a) {
 #pragma unroll
     for (int r = 0; r < DIM; ++r) s[p][r] = -0.5f * na[p][r];      // exact
     bool third;
-    filter_decide<DIM>(s[p], Rt, b1[p], b2[p], b3[p], near_tie_setup(false, 0.f, 0.f, 0.f), two[p], third);
+    filter_decide<DIM>(s[p], Rt, b1[p], b2[p], b3[p], nt, two[p], third);
     fall |= (base + (int64_t)p * kNnThreads + tid < a.n) && third;
   }
 
   // exact recipe: 64-bit key (distance bits, index inside the tile) — distances are non-negative floats, so one
   // unsigned compare is the (distance, lowest index) rule
   unsigned long long key[P];
+  float ebd[P], esec[P];                                      // SEC: smallest and second smallest exact distance evaluated
 #pragma unroll
-  for (int p = 0; p < P; ++p) key[p] = kKeyInit;
-  auto eval = [&](int j, unsigned long long& k, const float (&pt)[DIM]) {
+  for (int p = 0; p < P; ++p) { key[p] = kKeyInit; ebd[p] = INFINITY; esec[p] = INFINITY; }
+  auto eval = [&](int j, unsigned long long& k, float& bd, float& sc, const float (&pt)[DIM]) {
     const TP v = tile[j];
     float d;
     if constexpr (DIM == 2) d = dist2(pt[0], pt[1], v.x, v.y);
     else d = dist2(pt[0], pt[1], pt[2], v.x, v.y, v.z);
     const unsigned long long cand = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
     k = cand < k ? cand : k;
+    if constexpr (SEC) { sc = __builtin_amdgcn_fmed3f(bd, sc, d); bd = fminf(bd, d); }
   };
   if (cnt > 0) {
     if (__any(fall)) {
       for (int j = 0; j < cnt; ++j)                           // wave-uniform address: a broadcast read per target
 #pragma unroll
-        for (int p = 0; p < P; ++p) eval(j, key[p], s[p]);
+        for (int p = 0; p < P; ++p) eval(j, key[p], ebd[p], esec[p], s[p]);
     } else {
       int rot = lane;
       asm volatile("" : "+v"(rot));                           // opaque: the 32 rotated offsets are not worth 32 live registers
 #pragma unroll
       for (int p = 0; p < P; ++p) {
 #pragma unroll 8
-        for (int kk = 0; kk < FCH; ++kk) eval(i1[p] * FCH + ((kk + rot) & (FCH - 1)), key[p], s[p]);   // rotated start: all chunks begin on the same banks
+        for (int kk = 0; kk < FCH; ++kk) eval(i1[p] * FCH + ((kk + rot) & (FCH - 1)), key[p], ebd[p], esec[p], s[p]);   // rotated start: all chunks begin on the same banks
         if (__any(two[p])) {
           unsigned long long k2 = key[p];
+          float bd2 = ebd[p], sc2 = esec[p];
 #pragma unroll 8
-          for (int kk = 0; kk < FCH; ++kk) eval(i2[p] * FCH + ((kk + rot) & (FCH - 1)), k2, s[p]);
+          for (int kk = 0; kk < FCH; ++kk) eval(i2[p] * FCH + ((kk + rot) & (FCH - 1)), k2, bd2, sc2, s[p]);
           key[p] = two[p] ? k2 : key[p];
+          if constexpr (SEC) { ebd[p] = two[p] ? bd2 : ebd[p]; esec[p] = two[p] ? sc2 : esec[p]; }
         }
       }
     }
@@ -402,6 +423,8 @@ nn_tiled_filter_kernel(NnArgs a) {
     if (i >= a.n) continue;
     // padding targets evaluate to +inf and never win against a real one; the index becomes global here
     keys[i] = cnt > 0 ? key[p] + (unsigned long long)first_pt : kKeyInit;
+    // every target within the window of the split's winner was evaluated above, so the second smallest of those is what counts
+    if constexpr (SEC) a.sec[(int64_t)blockIdx.y * a.n + i] = cnt > 0 ? esec[p] : INFINITY;
   }
 }
 
@@ -444,6 +467,156 @@ moments_kernel(MomArgs a) {
       q[r] = (double)a.tgt[DIM * (int64_t)j + r];
     }
     acc.add(p, q, box);
+  }
+  acc.wave_reduce(box);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) acc.store(sh[wave]);
+  __syncthreads();
+  if (threadIdx.x < kAcc) {
+    const int k = threadIdx.x;
+    constexpr int kS = AccLayout<DIM>::kSums;
+    double v = sh[0][k];
+    for (int w = 1; w < kMomThreads / 64; ++w) {
+      if (k < kS) v += sh[w][k];
+      else if (k < kS + DIM) v = fmin(v, sh[w][k]);
+      else v = fmax(v, sh[w][k]);
+    }
+    a.partials[(size_t)blockIdx.x * kAcc + k] = v;
+  }
+}
+
+// ---- float64-exact mode of the three-launch path ------------------------------------------------------------
+// max |p|², max |t|² of the float32 clouds (once per call): bounds[0] = target, bounds[1] = source, as float bits via atomicMax
+__global__ void __launch_bounds__(256)
+cloud_bounds_kernel(const float* src, int64_t n, const float* tgt, int64_t m, int dim, int* bounds) {
+  float smax = 0.f, tmax = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float w = 0.f;
+    for (int r = 0; r < dim; ++r) { const float c = src[dim * i + r]; w = __builtin_fmaf(c, c, w); }
+    smax = fmaxf(smax, w);
+  }
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += (int64_t)gridDim.x * 256) {
+    float w = 0.f;
+    for (int r = 0; r < dim; ++r) { const float c = tgt[dim * j + r]; w = __builtin_fmaf(c, c, w); }
+    tmax = fmaxf(tmax, w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { smax = fmaxf(smax, __shfl_xor(smax, o, 64)); tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { atomicMax(&bounds[0], __float_as_int(tmax)); atomicMax(&bounds[1], __float_as_int(smax)); }
+}
+
+// moments_kernel in float64-exact mode: the keys and second smallest distances of the splits say which sources have a
+// near tie (lslam_device.h: NearTie); those are re-examined by the whole workgroup — every target whose float32 distance is
+// within the window is evaluated in float64 — and all pairs are accumulated from the float64 points.
+template <int DIM>
+__global__ void __launch_bounds__(kMomThreads)
+moments64_kernel(MomArgs a) {
+  constexpr int kAcc = AccLayout<DIM>::kTotal;
+  __shared__ double sh[kMomThreads / 64][kAcc];
+  __shared__ double s_ent[kMomThreads][8];                    // near-tie entries: lim, af[3], ad[3], source index (as double: < 2^31)
+  __shared__ unsigned long long s_best[kMomThreads];
+  __shared__ int s_bj[kMomThreads];
+  __shared__ int s_count;
+  if (a.state->done) return;
+  const bool box = (a.flags & kFlagNormalize) != 0;
+  const int tid = threadIdx.x;
+  double T[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) T[r][c] = a.state->T[4 * r + c];
+  double f2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < DIM; ++r)
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) f2 += T[r][c] * T[r][c];
+  const NearTie nt = near_tie_setup(true, sqrtf(a.bounds[0]) * 1.0001f, sqrtf(a.bounds[1]) * 1.0001f, sqrtf((float)f2) * 1.0001f);
+
+  PairAcc<DIM> acc;
+  acc.clear();
+  for (int64_t base = (int64_t)blockIdx.x * kMomThreads; base < a.n; base += (int64_t)gridDim.x * kMomThreads) {
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    const int64_t i = base + tid;
+    double pd[DIM];
+    if (i < a.n) {
+      unsigned long long kmin = kKeyInit;
+      float v1 = INFINITY, v2 = INFINITY;
+      for (int sp = 0; sp < a.splits; ++sp) {
+        const unsigned long long k = a.keys[(int64_t)sp * a.n + i];
+        kmin = k < kmin ? k : kmin;
+        const float b = (k == kKeyInit) ? INFINITY : __uint_as_float((unsigned)(k >> 32)), sc = a.sec[(int64_t)sp * a.n + i];
+        v2 = __builtin_amdgcn_fmed3f(v1, v2, b); v1 = fminf(v1, b);
+        v2 = __builtin_amdgcn_fmed3f(v1, v2, sc); v1 = fminf(v1, sc);
+      }
+      const uint32_t j = (uint32_t)(kmin & 0xffffffffull);
+      const double x = a.src64[DIM * i], y = a.src64[DIM * i + 1];
+      double z = 0.0;
+      if constexpr (DIM == 3) z = a.src64[DIM * i + 2];
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) {                          // icp.py:116 on the float64 point
+        double v = T[r][0] * x + T[r][1] * y + T[r][3];
+        if constexpr (DIM == 3) v += T[r][2] * z;
+        pd[r] = v;
+      }
+      const float lim = near_lim(v1, nt);
+      if (v2 <= lim) {                                         // near tie: the workgroup decides it below
+        const int e = atomicAdd(&s_count, 1);
+        s_ent[e][0] = (double)lim;
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) {
+          double v = T[r][0] * (double)a.src[DIM * i] + T[r][1] * (double)a.src[DIM * i + 1] + T[r][3];     // what the search saw
+          if constexpr (DIM == 3) v += T[r][2] * (double)a.src[DIM * i + 2];
+          s_ent[e][1 + r] = (double)(float)v;
+          s_ent[e][4 + r] = pd[r];
+        }
+        s_ent[e][7] = (double)i;
+        s_best[e] = ~0ull;
+        s_bj[e] = 0x7fffffff;
+      } else {
+        if (a.out_corr) a.out_corr[i] = (int32_t)j;
+        double q[DIM];
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) q[r] = a.tgt64[DIM * (int64_t)j + r];
+        acc.add(pd, q, box);
+      }
+    }
+    __syncthreads();
+    const int ne = s_count;
+    if (ne > 0) {
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int e = 0; e < ne; ++e) {
+          const float lim = (float)s_ent[e][0];
+          float ap[DIM];
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) ap[r] = (float)s_ent[e][1 + r];
+          for (int64_t j = tid; j < a.m; j += kMomThreads) {
+            float d;
+            if constexpr (DIM == 2) d = dist2(ap[0], ap[1], a.tgt[2 * j], a.tgt[2 * j + 1]);
+            else d = dist2(ap[0], ap[1], ap[2], a.tgt[3 * j], a.tgt[3 * j + 1], a.tgt[3 * j + 2]);
+            if (d <= lim) {                                    // a candidate: float64 decides (lowest index on float64 ties)
+              double ev = 0.0;
+#pragma unroll
+              for (int r = 0; r < DIM; ++r) { const double df = s_ent[e][4 + r] - a.tgt64[DIM * j + r]; ev += df * df; }
+              const unsigned long long bits = (unsigned long long)__double_as_longlong(ev);
+              if (pass == 0) atomicMin(&s_best[e], bits);
+              else if (bits == s_best[e]) atomicMin(&s_bj[e], (int)j);
+            }
+          }
+        }
+        __syncthreads();
+      }
+      if (tid < ne) {                                          // thread e finishes entry e
+        const int64_t i = (int64_t)s_ent[tid][7];
+        const int bj = s_bj[tid];
+        if (a.out_corr) a.out_corr[i] = bj;
+        double p[DIM], q[DIM];
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) { p[r] = s_ent[tid][4 + r]; q[r] = a.tgt64[DIM * (int64_t)bj + r]; }
+        acc.add(p, q, box);
+      }
+      __syncthreads();
+    }
   }
   acc.wave_reduce(box);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -561,23 +734,36 @@ hipError_t launch_nn(NnArgs a, int dim, const NnGeometry& g, hipStream_t stream)
   if (a.n <= 0) return hipSuccess;
   const dim3 grid(g.grid_x, (unsigned)g.splits), block(kNnThreads);
   const bool fuse = a.fuse_state != nullptr;                // the caller sets it only when g.P == 1
-  if (dim == 2) {
-    if (fuse) hipLaunchKernelGGL((nn_tiled_kernel<2, 1, true>), grid, block, g.smem, stream, a);
-    else if (g.filter && g.P == 2) hipLaunchKernelGGL((nn_tiled_filter_kernel<2, 2>), grid, block, g.smem, stream, a);
-    else if (g.filter) hipLaunchKernelGGL((nn_tiled_filter_kernel<2, 4>), grid, block, g.smem, stream, a);
-    else if (g.P == 1) hipLaunchKernelGGL((nn_tiled_kernel<2, 1, false>), grid, block, g.smem, stream, a);
-    else if (g.P == 2) hipLaunchKernelGGL((nn_tiled_kernel<2, 2, false>), grid, block, g.smem, stream, a);
-    else hipLaunchKernelGGL((nn_tiled_kernel<2, 4, false>), grid, block, g.smem, stream, a);
-  } else {
-    // the expanded-form filter sweep is the default of the 3-D search with several points per lane
-    // (LSLAM_ICP_FILTER=0: direct-difference sweep); nn_geometry decides, the two kernels need different splits
-    if (fuse) hipLaunchKernelGGL((nn_tiled_kernel<3, 1, true>), grid, block, g.smem, stream, a);
-    else if (g.filter && g.P == 2) hipLaunchKernelGGL((nn_tiled_filter_kernel<3, 2>), grid, block, g.smem, stream, a);
-    else if (g.filter) hipLaunchKernelGGL((nn_tiled_filter_kernel<3, 4>), grid, block, g.smem, stream, a);
-    else if (g.P == 1) hipLaunchKernelGGL((nn_tiled_kernel<3, 1, false>), grid, block, g.smem, stream, a);
-    else if (g.P == 2) hipLaunchKernelGGL((nn_tiled_kernel<3, 2, false>), grid, block, g.smem, stream, a);
-    else hipLaunchKernelGGL((nn_tiled_kernel<3, 4, false>), grid, block, g.smem, stream, a);
-  }
+  const bool sec = a.sec != nullptr;                        // float64-exact mode (never with the fused tail)
+  if (fuse && sec) return hipErrorInvalidValue;
+  // the expanded-form filter sweep is the default of the search with several points per lane (LSLAM_ICP_FILTER=0:
+  // direct-difference sweep); nn_geometry decides, the two kernels need different splits
+#define LSLAM_NN_LAUNCH(D)                                                                                                        \
+  do {                                                                                                                            \
+    if (fuse) hipLaunchKernelGGL((nn_tiled_kernel<D, 1, true>), grid, block, g.smem, stream, a);                                  \
+    else if (g.filter && g.P == 2) { if (sec) hipLaunchKernelGGL((nn_tiled_filter_kernel<D, 2, true>), grid, block, g.smem, stream, a);  \
+                                     else hipLaunchKernelGGL((nn_tiled_filter_kernel<D, 2>), grid, block, g.smem, stream, a); }   \
+    else if (g.filter) { if (sec) hipLaunchKernelGGL((nn_tiled_filter_kernel<D, 4, true>), grid, block, g.smem, stream, a);       \
+                         else hipLaunchKernelGGL((nn_tiled_filter_kernel<D, 4>), grid, block, g.smem, stream, a); }               \
+    else if (g.P == 1) { if (sec) hipLaunchKernelGGL((nn_tiled_kernel<D, 1, false, true>), grid, block, g.smem, stream, a);       \
+                         else hipLaunchKernelGGL((nn_tiled_kernel<D, 1, false>), grid, block, g.smem, stream, a); }               \
+    else if (g.P == 2) { if (sec) hipLaunchKernelGGL((nn_tiled_kernel<D, 2, false, true>), grid, block, g.smem, stream, a);       \
+                         else hipLaunchKernelGGL((nn_tiled_kernel<D, 2, false>), grid, block, g.smem, stream, a); }               \
+    else { if (sec) hipLaunchKernelGGL((nn_tiled_kernel<D, 4, false, true>), grid, block, g.smem, stream, a);                     \
+           else hipLaunchKernelGGL((nn_tiled_kernel<D, 4, false>), grid, block, g.smem, stream, a); }                             \
+  } while (0)
+  if (dim == 2) LSLAM_NN_LAUNCH(2); else LSLAM_NN_LAUNCH(3);
+#undef LSLAM_NN_LAUNCH
+  return hipGetLastError();
+}
+
+hipError_t launch_cloud_bounds(const float* src, int64_t n, const float* tgt, int64_t m, int dim, float* bounds, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(bounds, 0, 8, stream);
+  if (e != hipSuccess) return e;
+  const int64_t mx = n > m ? n : m;
+  int blocks = (int)((mx + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(cloud_bounds_kernel, dim3(blocks), dim3(256), 0, stream, src, n, tgt, m, dim, reinterpret_cast<int*>(bounds));
   return hipGetLastError();
 }
 
@@ -595,6 +781,11 @@ int moments_rows(int64_t n) {
 }
 
 hipError_t launch_moments(MomArgs a, int dim, int rows, hipStream_t stream) {
+  if (a.src64) {                                            // float64-exact mode
+    if (dim == 2) hipLaunchKernelGGL(moments64_kernel<2>, dim3(rows), dim3(kMomThreads), 0, stream, a);
+    else hipLaunchKernelGGL(moments64_kernel<3>, dim3(rows), dim3(kMomThreads), 0, stream, a);
+    return hipGetLastError();
+  }
   if (dim == 2) hipLaunchKernelGGL(moments_kernel<2>, dim3(rows), dim3(kMomThreads), 0, stream, a);
   else hipLaunchKernelGGL(moments_kernel<3>, dim3(rows), dim3(kMomThreads), 0, stream, a);
   return hipGetLastError();

@@ -446,17 +446,14 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
       }
       Moments mo;
       combine_partials<3>(tot, 1, kAcc, box, mo);
-      double Tstep[16], Tprev[16], Tnew[16];
-      step_from_moments(mo, false, Tstep);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) Tprev[i] = sh_T[i];
-      matmul4(Tstep, Tprev, Tnew);
+      double R[9], pb[3], qb[3];
+      step_parts(mo, false, R, pb, qb);
+      const double tn = step_times_prev_lane(R, pb, qb, sh_T, sh_red, lane);      // one element of T_step·T_prev per lane (the wave rows in sh_red are consumed)
       const double err = error_from_moments(mo, box);
       StopState st = *sh_stop;
       const bool stop = stop_after_iteration(st, err, args.epsilon, args.stopping_thresh, args.max_iters);
+      if (lane < 16) sh_T[lane] = tn;
       if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sh_T[i] = Tnew[i];
         sh_flag[0] = stop ? 1 : 0;
         *sh_stop = st;
         *sh_err = err;

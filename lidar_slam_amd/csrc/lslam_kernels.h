@@ -131,6 +131,10 @@ struct NnArgs {
   uint32_t flags;
   double epsilon, stopping_thresh;
   int32_t max_iters;
+  // float64-exact mode (three-launch path only): second smallest distance per (split, source), laid out like keys, and
+  // {max |t|², max |p|²} of the float32 clouds (launch_cloud_bounds)
+  float* sec;
+  const float* bounds;
 };
 
 struct NnGeometry {
@@ -152,6 +156,11 @@ struct MomArgs {
   double* partials;              // rows x AccLayout<DIM>::kTotal
   int32_t* out_corr;             // or nullptr
   uint32_t flags;
+  // float64-exact mode: the float64 clouds, the target size, the splits' second smallest distances, the clouds' bounds
+  const double* src64; const double* tgt64;
+  int64_t m;
+  const float* sec;
+  const float* bounds;
 };
 
 struct SolveArgs {
@@ -165,10 +174,30 @@ struct SolveArgs {
 
 NnGeometry nn_geometry(int dim, int64_t n, int64_t m);
 hipError_t launch_nn(NnArgs a, int dim, const NnGeometry& g, hipStream_t stream);
+hipError_t launch_cloud_bounds(const float* src, int64_t n, const float* tgt, int64_t m, int dim, float* bounds, hipStream_t stream);
 hipError_t launch_nn_finalize(const unsigned long long* keys, int64_t n, int splits, int32_t* out_idx, float* out_d2, hipStream_t stream);
 int moments_rows(int64_t n);
 hipError_t launch_moments(MomArgs a, int dim, int rows, hipStream_t stream);
 hipError_t launch_solve(SolveArgs a, int dim, hipStream_t stream);
+
+// ---- one LiDAR-sized pair iterated inside ONE launch by co-resident workgroups (lslam_icp_coop.hip) ----------
+struct CoopArgs {
+  const float* src; int32_t n;
+  const float* tgt; int32_t m;
+  const double* src64;           // float64-exact mode: both set, or both nullptr
+  const double* tgt64;
+  LargeState* state;             // in: T = the start transform; out: T, err, stop, done = 1
+  unsigned long long* gran;      // icp_coop_gran_bytes(): the workgroups' moment rows, zeroed by the launcher
+  unsigned* failed;              // set to 1 if a workgroup gave up waiting for the others (never on a healthy device)
+  int32_t* out_corr;             // or nullptr
+  uint32_t flags;
+  double epsilon, stopping_thresh;
+  int32_t max_iters;
+  uint32_t tile_bytes, tile64_bytes, gran_bytes;   // filled by the launcher
+};
+bool icp_coop_supported(int dim, int64_t n, int64_t m, bool f64);
+size_t icp_coop_gran_bytes(int dim, int64_t n);
+hipError_t launch_icp_coop(CoopArgs a, int dim, hipStream_t stream);
 
 // ---- whole-chip path with exact box pruning (lslam_icp_large_pruned.hip) ------------------------------
 struct LpT { float m[3][4]; };

@@ -144,16 +144,21 @@ LSLAM_HD void polar_3d(const double S[9], double R[9]) {
     for (int j = 0; j < 3; ++j) R[3 * i + j] = v1[i] * u1[j] + v2[i] * u2[j] + v3[i] * u3[j];
 }
 
-// T_step (4x4 row-major) from the moments.  S = Σpqᵀ − Σp Σqᵀ / n is the centred
-// cross-covariance Xcᵀ Yc of icp.py:58-61.
-LSLAM_HD void step_from_moments(const Moments& m, bool planar, double Tstep[16]) {
-  double S[9], R[9];
+// The pieces of T_step from the moments: R (3x3 row-major), the centroids pb = Σp/n, qb = Σq/n.
+// S = Σpqᵀ − Σp Σqᵀ / n is the centred cross-covariance Xcᵀ Yc of icp.py:58-61.
+LSLAM_HD void step_parts(const Moments& m, bool planar, double R[9], double pb[3], double qb[3]) {
+  double S[9];
   const double inv_n = 1.0 / m.n;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) S[3 * i + j] = m.spq[3 * i + j] - m.sp[i] * m.sq[j] * inv_n;
   if (planar) polar_planar(S, R); else polar_3d(S, R);
-  double pb[3], qb[3];
   for (int i = 0; i < 3; ++i) { pb[i] = m.sp[i] * inv_n; qb[i] = m.sq[i] * inv_n; }
+}
+
+// T_step (4x4 row-major): rotation R, translation qb − R·pb (icp.py:65-72).
+LSLAM_HD void step_from_moments(const Moments& m, bool planar, double Tstep[16]) {
+  double R[9], pb[3], qb[3];
+  step_parts(m, planar, R, pb, qb);
   for (int i = 0; i < 3; ++i) {
     for (int j = 0; j < 3; ++j) Tstep[4 * i + j] = R[3 * i + j];
     Tstep[4 * i + 3] = qb[i] - (R[3 * i] * pb[0] + R[3 * i + 1] * pb[1] + R[3 * i + 2] * pb[2]);

@@ -37,6 +37,10 @@ def yaw_starts(source_pc, target_pc, n_starts=24):
     return T
 
 
+def _cloud_dtype(a, b):
+    return np.float32 if (np.asarray(a).dtype == np.float32 and np.asarray(b).dtype == np.float32) else np.float64
+
+
 def register_multi_start(source_pc, target_pc, n_starts=24, epsilon=0.001, voxel_size=0.005,
                          downsample_above=20000, max_iters=2000, stopping_thresh=0.0001,
                          return_all=False):
@@ -55,14 +59,17 @@ def register_multi_start(source_pc, target_pc, n_starts=24, epsilon=0.001, voxel
         src, tgt = source_pc, target_pc
     n, m, S = src.shape[0], tgt.shape[0], init.shape[0]
     d = 2 if (src.shape[1] == 2 and tgt.shape[1] == 2) else 3
-    s32 = np.ascontiguousarray(icp._xyz(src)[:, :d], dtype=np.float32)
-    t32 = np.ascontiguousarray(icp._xyz(tgt)[:, :d], dtype=np.float32)
+    # float64 clouds run in float64-exact mode (the reference's float64 search); float32 input is searched as it is
+    dtype = _cloud_dtype(source_pc, target_pc)
+    s32 = np.ascontiguousarray(icp._xyz(src)[:, :d], dtype=dtype)
+    t32 = np.ascontiguousarray(icp._xyz(tgt)[:, :d], dtype=dtype)
     if n * m > SEQUENTIAL_PAIR_EVALS:
         poses, errors, iters = np.empty((S, 4, 4)), np.empty(S), np.zeros(S, dtype=np.int32)
+        entry = lib().lslam_icp_large_f64 if dtype == np.float64 else lib().lslam_icp_large
         for k in range(S):
-            check(lib().lslam_icp_large(ptr(s32), n, ptr(t32), m, d, ptr(np.ascontiguousarray(init[k])), float(epsilon),
-                                        float(stopping_thresh), int(max_iters), ICP_NORMALIZE_ERROR, ptr(poses[k]),
-                                        ptr(errors[k:k + 1]), ptr(iters[k:k + 1]), None, icp._DEVICE))
+            check(entry(ptr(s32), n, ptr(t32), m, d, ptr(np.ascontiguousarray(init[k])), float(epsilon),
+                        float(stopping_thresh), int(max_iters), ICP_NORMALIZE_ERROR, ptr(poses[k]),
+                        ptr(errors[k:k + 1]), ptr(iters[k:k + 1]), None, icp._DEVICE))
     else:
         r = icp_batch(np.tile(s32, (S, 1)), np.arange(S + 1, dtype=np.int64) * n, np.tile(t32, (S, 1)),
                       np.arange(S + 1, dtype=np.int64) * m, init, epsilon=epsilon, max_iters=max_iters,
@@ -90,8 +97,9 @@ def register_multi_start_many(source_pc, target_pcs, n_starts=24, epsilon=0.001,
             s_ds, t_ds = icp.voxel_downsample(source_pc, voxel_size), icp.voxel_downsample(t, voxel_size)
         else:
             s_ds, t_ds = source_pc, t
-        src_blocks.append(np.ascontiguousarray(icp._xyz(s_ds)[:, :d], dtype=np.float32))
-        tgt_blocks.append(np.ascontiguousarray(icp._xyz(t_ds)[:, :d], dtype=np.float32))
+        dtype = _cloud_dtype(source_pc, t)
+        src_blocks.append(np.ascontiguousarray(icp._xyz(s_ds)[:, :d], dtype=dtype))
+        tgt_blocks.append(np.ascontiguousarray(icp._xyz(t_ds)[:, :d], dtype=dtype))
         n_src.append(src_blocks[-1].shape[0]); n_tgt.append(tgt_blocks[-1].shape[0])
     if not targets:
         return []

@@ -4,10 +4,11 @@ Every function keeps the reference's name, argument order, defaults and return c
 (modules/icp.py:4,29,43,76,100,123-133); the arithmetic runs in the HIP kernels of
 ``liblslam_hip.so`` (no CPU fallback — without the library or a GPU the calls raise).
 
-Differences a caller can observe: points are rounded to float32 and the
-nearest-neighbour search is an exact float32 brute force (lowest index on distance ties, where
-the KD-tree picks an arbitrary one); moments, solve, error and stop rules are float64.
-Relative poses agree with the reference within 5e-5 m / 5e-6 rad.
+Differences a caller can observe: none beyond float64 summation order.  The device searches in
+float32 but decides every near tie on the float64 points (float64-exact mode), so the correspondences are those of
+the reference's float64 search — lowest index on exact distance ties, where the KD-tree picks an arbitrary one —
+and moments, solve, error and stop rules are float64 on the float64 points: T and error agree with the reference to
+~1e-12.  (float32 input arrays are searched as they are: exact float32 nearest neighbours.)
 """
 from __future__ import annotations
 
@@ -139,14 +140,18 @@ def _solve(pc1, pc2, init_transform, epsilon, max_iters, stopping_thresh, normal
 
 
 def _solve_near(src, tgt, T0, epsilon, max_iters, stopping_thresh, normalize_error):
+    """float64 clouds go to the float64-exact entry points (``lslam_icp_*_f64``): the device searches in float32 and
+    decides every near tie on the float64 points, so the correspondences are those of the reference's float64 search
+    (modules/icp.py:29-41).  Clouds that ARE float32 are searched as they are (exact float32 nearest neighbours)."""
     planar = src.shape[1] == 2 and tgt.shape[1] == 2 and _keeps_planar(T0)
+    dtype = np.float32 if (src.dtype == np.float32 and tgt.dtype == np.float32) else np.float64
     if planar:
-        s32 = np.ascontiguousarray(src, dtype=np.float32)
-        t32 = np.ascontiguousarray(tgt, dtype=np.float32)
+        s = np.ascontiguousarray(src, dtype=dtype)
+        t = np.ascontiguousarray(tgt, dtype=dtype)
     else:
-        s32 = np.ascontiguousarray(_xyz(src), dtype=np.float32)
-        t32 = np.ascontiguousarray(_xyz(tgt), dtype=np.float32)
-    n, m, dim = s32.shape[0], t32.shape[0], s32.shape[1]
+        s = np.ascontiguousarray(_xyz(src), dtype=dtype)
+        t = np.ascontiguousarray(_xyz(tgt), dtype=dtype)
+    n, m, dim = s.shape[0], t.shape[0], s.shape[1]
     if m == 0:
         raise IndexError("index 0 is out of bounds for axis 0 with size 0 (empty target cloud)")
     if n > 0 and n * m > LARGE_PAIR_EVALS:
@@ -155,11 +160,11 @@ def _solve_near(src, tgt, T0, epsilon, max_iters, stopping_thresh, normalize_err
         it = np.empty(1, dtype=np.int32)
         corr = np.empty(n, dtype=np.int32)
         flags = (_lib.ICP_NORMALIZE_ERROR if normalize_error else 0) | _lib.search_flags(PRUNE)
-        check(lib().lslam_icp_large(ptr(s32), n, ptr(t32), m, dim, ptr(T0), float(epsilon),
-                                    float(stopping_thresh), int(max_iters), flags, ptr(T), ptr(err),
-                                    ptr(it), ptr(corr), _DEVICE))
+        entry = lib().lslam_icp_large_f64 if dtype == np.float64 else lib().lslam_icp_large
+        check(entry(ptr(s), n, ptr(t), m, dim, ptr(T0), float(epsilon), float(stopping_thresh), int(max_iters), flags,
+                    ptr(T), ptr(err), ptr(it), ptr(corr), _DEVICE))
         return T, np.float64(err[0]), corr.astype(np.int64)
-    r = icp_batch(s32, np.array([0, n], dtype=np.int64), t32, np.array([0, m], dtype=np.int64), T0[None],
+    r = icp_batch(s, np.array([0, n], dtype=np.int64), t, np.array([0, m], dtype=np.int64), T0[None],
                   epsilon=epsilon, max_iters=max_iters, stopping_thresh=stopping_thresh,
                   normalize_error=normalize_error, return_correspondences=True, device=_DEVICE, prune=PRUNE)
     return r.T[0], np.float64(r.error[0]), r.correspondences.astype(np.int64)

@@ -19,6 +19,39 @@ def search_default(request, monkeypatch):
     return request.param
 
 
+class Precision:
+    """how a test hands its clouds to the library and what it may then demand:
+    f32  float32 clouds: exact float32 nearest neighbours — identical to the oracle's DEVICE recipe (integer outputs
+         bit-exact), relative poses within 5e-5 m / 5e-6 rad of the float64 reference;
+    f64  float64 clouds: float64-exact mode — correspondences identical to the reference's float64 search (the oracle's
+         f64 recipe, brute force, lowest index on exact ties) and T within 1e-9 of the reference itself."""
+
+    def __init__(self, name):
+        self.name = name
+        self.dtype = np.float32 if name == "f32" else np.float64
+        self.recipe = "device" if name == "f32" else "f64"
+        self.tol_t, self.tol_r = (TOL_TRANS, TOL_ROT) if name == "f32" else (1e-9, 1e-9)
+        self.err_rtol = 1e-6 if name == "f32" else 1e-10
+
+    def cast(self, a):
+        return np.ascontiguousarray(a, dtype=self.dtype)
+
+    def pack(self, clouds):
+        from lidar_slam_amd.batch import pack_clouds
+        return pack_clouds(list(clouds), dtype=self.dtype)
+
+    def close(self, T, T_ref, scale=1.0):
+        assert np.abs(T[:3, 3] - T_ref[:3, 3]).max() < self.tol_t * scale
+        assert np.abs(T[:3, :3] - T_ref[:3, :3]).max() < self.tol_r * scale
+        assert np.array_equal(T[3], T_ref[3])
+
+
+@pytest.fixture(autouse=True, params=["f32", "f64"])
+def prec(request):
+    """every test of this file also runs in both precision modes"""
+    return Precision(request.param)
+
+
 @pytest.fixture(scope="module")
 def icp():
     import lidar_slam_amd
@@ -34,38 +67,39 @@ def close_to_reference(T, T_ref):
     assert np.array_equal(T[3], T_ref[3])
 
 
-def batch_of(g, key_src="src", with_init=True):
-    from lidar_slam_amd.batch import pack_clouds
+def batch_of(g, prec, key_src="src", with_init=True):
     srcs = split(g[key_src], g["src_off"])
-    flat, off = pack_clouds(srcs)
+    flat, off = prec.pack(srcs)
     S = len(srcs)
-    tgt = np.ascontiguousarray(np.tile(g["tgt"], (S, 1)), dtype=np.float32)
+    tgt = prec.cast(np.tile(g["tgt"], (S, 1)))
     toff = np.arange(S + 1, dtype=np.int64) * g["tgt"].shape[0]
     init = g["init"] if with_init else np.tile(np.eye(4), (S, 1, 1))
     return srcs, flat, off, tgt, toff, init
 
 
-def test_planar_pairs_batched_vs_golden_and_oracle(icp):
+def test_planar_pairs_batched_vs_golden_and_oracle(icp, prec):
     from lidar_slam_amd.batch import icp_batch
     from oracle import icp_oracle
     g = golden("icp_planar.npz")
-    srcs, flat, off, tgt, toff, init = batch_of(g)
+    srcs, flat, off, tgt, toff, init = batch_of(g, prec)
     r = icp_batch(flat, off, tgt, toff, init, epsilon=float(g["epsilon"]), return_correspondences=True)
-    np.testing.assert_array_equal(r.iterations, g["iterations"])          # same number of iterations
+    np.testing.assert_array_equal(r.iterations, g["iterations"])          # same number of iterations as the reference
+    np.testing.assert_array_equal(r.correspondences, g["corr"])           # the REFERENCE's correspondences, every one
     for k, src in enumerate(srcs):
-        close_to_reference(r.T[k], g["T"][k])
-        assert abs(r.error[k] - g["error"][k]) < 1e-6 * max(1.0, g["error"][k])
-        o = icp_oracle.run_icp_full(src, g["tgt"], init[k], epsilon=float(g["epsilon"]), recipe="device")
+        prec.close(r.T[k], g["T"][k])
+        assert abs(r.error[k] - g["error"][k]) < prec.err_rtol * max(1.0, g["error"][k])
+        o = icp_oracle.run_icp_full(src, g["tgt"], init[k], epsilon=float(g["epsilon"]), recipe=prec.recipe, nn="brute")
         np.testing.assert_array_equal(r.correspondences[off[k]:off[k + 1]], o.correspondences)   # bit-exact indices
         np.testing.assert_allclose(r.T[k], o.T, atol=1e-10)
         np.testing.assert_allclose(r.error[k], o.error, rtol=1e-10)
 
 
-def test_run_icp_call_surface(icp):
+def test_run_icp_call_surface(icp, prec):
     g = golden("icp_planar.npz")
     src = g["src"][: g["src_off"][1]]
     src_before = src.copy()
     T = icp.run_icp(src, g["tgt"], init_transform=g["init"][0], epsilon=0.001)
+    close_to_reference = Precision("f64").close                # float64 arrays in: float64-exact mode, whatever `prec` is
     assert isinstance(T, np.ndarray) and T.shape == (4, 4) and T.dtype == np.float64
     T2, e = icp.run_icp(src, g["tgt"], g["init"][0], 0.001, return_error=True)
     T3, c = icp.run_icp(src, g["tgt"], g["init"][0], 0.001, return_correspondences=True)
@@ -74,79 +108,81 @@ def test_run_icp_call_surface(icp):
     assert e == e4 and isinstance(e, np.float64) and c.dtype == np.int64 and np.array_equal(c, c4)
     assert np.array_equal(src, src_before)                     # inputs never mutated (I8)
     close_to_reference(T, g["T"][0])
-    # float32 input is accepted (promoted in the reference)
-    close_to_reference(icp.run_icp(src.astype(np.float32), g["tgt"].astype(np.float32), g["init"][0], 0.001), g["T"][0])
+    # float32 input is accepted (promoted in the reference; searched as float32 here)
+    Precision("f32").close(icp.run_icp(src.astype(np.float32), g["tgt"].astype(np.float32), g["init"][0], 0.001), g["T"][0])
 
 
-def test_forced_50_iterations(icp):
+def test_forced_50_iterations(icp, prec):
     from lidar_slam_amd.batch import icp_batch
     g = golden("icp_forced50.npz")
-    srcs, flat, off, tgt, toff, init = batch_of(g)
+    srcs, flat, off, tgt, toff, init = batch_of(g, prec)
     r = icp_batch(flat, off, tgt, toff, init, epsilon=0.0, stopping_thresh=0.0, max_iters=49)
     assert r.iterations.tolist() == [50, 50]
     for k in range(2):
-        close_to_reference(r.T[k], g["T"][k])
+        prec.close(r.T[k], g["T"][k])
 
 
-def test_loop_closure_style_normalized_error(icp):
+def test_loop_closure_style_normalized_error(icp, prec):
     g = golden("icp_loopclose.npz")
     srcs, corrs = split(g["src"], g["src_off"]), split(g["corr"], g["src_off"])
     for k, src in enumerate(srcs):
-        T, err, corr = icp.run_icp(src, g["tgt"], epsilon=float(g["epsilon"][k]), return_error=True,
+        T, err, corr = icp.run_icp(prec.cast(src), prec.cast(g["tgt"]), epsilon=float(g["epsilon"][k]), return_error=True,
                                    normalize_error=True, return_correspondences=True)
-        close_to_reference(T, g["T"][k])
-        assert abs(err - g["error"][k]) < 1e-6 * g["error"][k] + 1e-12
-        assert np.mean(corr == corrs[k]) > 0.995
+        prec.close(T, g["T"][k])
+        assert abs(err - g["error"][k]) < prec.err_rtol * g["error"][k] + 1e-12
+        np.testing.assert_array_equal(corr, corrs[k])             # the reference's correspondences, every one
 
 
-def test_3d_multistart_vs_golden_and_oracle(icp):
+def test_3d_multistart_vs_golden_and_oracle(icp, prec):
     from lidar_slam_amd.batch import icp_batch
     from oracle import c_oracle
     g = golden("icp_3d.npz")
     S = g["init"].shape[0]
     n, m = g["src"].shape[0], g["tgt"].shape[0]
-    src = np.ascontiguousarray(np.tile(g["src"], (S, 1)), dtype=np.float32)
-    tgt = np.ascontiguousarray(np.tile(g["tgt"], (S, 1)), dtype=np.float32)
+    src = prec.cast(np.tile(g["src"], (S, 1)))
+    tgt = prec.cast(np.tile(g["tgt"], (S, 1)))
     r = icp_batch(src, np.arange(S + 1) * n, tgt, np.arange(S + 1) * m, g["init"], epsilon=0.001,
                   normalize_error=True, return_correspondences=True)
     np.testing.assert_array_equal(r.iterations, g["iterations"])
+    np.testing.assert_array_equal(r.correspondences, g["corr"].reshape(-1))      # the reference's correspondences, every one
     for k in range(S):
-        close_to_reference(r.T[k], g["T"][k])
+        prec.close(r.T[k], g["T"][k])
         To, eo, co, ito = c_oracle.run_icp(g["src"], g["tgt"], g["init"][k], epsilon=0.001, normalize_error=True,
-                                           recipe="device")
+                                           recipe=prec.recipe)
         np.testing.assert_array_equal(r.correspondences[k * n:(k + 1) * n], co)
         np.testing.assert_allclose(r.T[k], To, atol=1e-9)
         np.testing.assert_allclose(r.error[k], eo, rtol=1e-9)
 
 
 @pytest.mark.parametrize("sequential", [False, True])
-def test_register_multi_start_matches_reference_loop(icp, sequential, monkeypatch):
-    """24 yaw starts of code/icp_warm_up/test_icp.py:66-92: one batched launch, or whole-chip runs back to back"""
+def test_register_multi_start_matches_reference_loop(icp, sequential, monkeypatch, prec):
+    """24 yaw starts of code/icp_warm_up/test_icp.py:66-92: one batched launch, or whole-chip runs back to back.
+    float64 clouds (float64-exact mode): EVERY start equals the reference's, within 1e-9 — no exception.  float32 clouds:
+    rounding the inputs flips a correspondence in one wrong-basin start (start 15, 1.1e-4 rad off); that start must
+    then equal the float64 algorithm run on the ROUNDED clouds — the documented limit of handing over float32 points."""
     from lidar_slam_amd import icp_warm_up as W
     g, m = golden("icp_3d.npz"), golden("icp_multistart.npz")
     if sequential:
         monkeypatch.setattr(W, "SEQUENTIAL_PAIR_EVALS", 0)
     from oracle import icp_oracle
-    pose, err, poses, errors, iters = W.register_multi_start(g["src"], g["tgt"], return_all=True)
+    pose, err, poses, errors, iters = W.register_multi_start(prec.cast(g["src"]), prec.cast(g["tgt"]), return_all=True)
     np.testing.assert_array_equal(iters, m["iterations"])
     init = W.yaw_starts(g["src"], g["tgt"])
     r32 = lambda a: a.astype(np.float32).astype(np.float64)
     sensitive = 0
     for k in range(24):
-        if np.abs(poses[k][:3, :3] - m["T"][k][:3, :3]).max() < TOL_ROT:
-            close_to_reference(poses[k], m["T"][k])
-            assert abs(errors[k] - m["error"][k]) < 2e-5 * m["error"][k]
+        if np.abs(poses[k][:3, :3] - m["T"][k][:3, :3]).max() < prec.tol_r:
+            prec.close(poses[k], m["T"][k])
+            assert abs(errors[k] - m["error"][k]) < 20 * prec.err_rtol * m["error"][k]
             continue
-        # a wrong-basin start where rounding the INPUT clouds to float32 flips a correspondence: the float64
-        # restatement fed the rounded clouds leaves the reference by the same amount, and the device follows it
         sensitive += 1
         o = icp_oracle.run_icp_full(r32(g["src"]), r32(g["tgt"]), init[k], epsilon=0.001, normalize_error=True)
         assert np.abs(o.T[:3, :3] - m["T"][k][:3, :3]).max() > TOL_ROT
-        close_to_reference(poses[k], o.T)
-    assert sensitive <= 1
+        prec.close(poses[k], o.T)
+    assert sensitive == (0 if prec.name == "f64" else 1)
     assert int(np.argmin(errors)) == int(m["best"])
-    close_to_reference(pose, m["best_pose"])
-    assert isinstance(err, np.float64) and abs(err - m["best_error"]) < 2e-5 * m["best_error"]
+    prec.close(pose, m["best_pose"])
+    assert isinstance(err, np.float64) and abs(err - m["best_error"]) < 20 * prec.err_rtol * m["best_error"]
     np.testing.assert_allclose(W.yaw_starts(g["src"], g["tgt"])[[0, 4, 5, 13]], g["init"], atol=1e-12)
 
 
@@ -163,7 +199,7 @@ def test_register_multi_start_many_equals_one_target_at_a_time(icp):
     assert W.register_multi_start_many(g["src"], []) == []
 
 
-def test_clouds_far_from_the_origin_are_centred_before_rounding(icp):
+def test_clouds_far_from_the_origin_are_centred_before_rounding(icp, prec):
     """at |coordinate| = 1e5 m a float32 holds 8 mm; run_icp shifts such clouds in float64 first"""
     from oracle import icp_oracle
     rng = np.random.default_rng(3)
@@ -172,6 +208,8 @@ def test_clouds_far_from_the_origin_are_centred_before_rounding(icp):
     R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
     c = tgt.mean(0)
     src = (tgt[:250] - c) @ R.T + c + np.array([0.03, -0.02]) + rng.normal(0, 0.002, (250, 2))
+    if prec.name == "f32":
+        pytest.skip("float32 arrays cannot hold these coordinates; run_icp shifts float64 input before rounding")
     T, err, corr = icp.run_icp(src, tgt, return_error=True, return_correspondences=True, epsilon=1e-9)
     o = icp_oracle.run_icp_full(src, tgt, None, epsilon=1e-9)
     assert np.array_equal(corr, o.correspondences)
@@ -181,7 +219,9 @@ def test_clouds_far_from_the_origin_are_centred_before_rounding(icp):
     assert np.abs(T[:3, :3] - o.T[:3, :3]).max() < TOL_ROT
 
 
-def test_get_transform_get_error_get_correspondences(icp):
+def test_get_transform_get_error_get_correspondences(icp, prec):
+    if prec.name == "f64":
+        pytest.skip("these operators have one precision")
     from oracle import c_oracle
     g = golden("kabsch.npz")
     for k, (p, q) in enumerate(zip(split(g["p"], g["off"]), split(g["q"], g["off"]))):
@@ -197,41 +237,40 @@ def test_get_transform_get_error_get_correspondences(icp):
     assert idx.dtype == np.int64 and np.array_equal(idx, ref)
 
 
-def test_icp_iteration_is_one_step(icp):
+def test_icp_iteration_is_one_step(icp, prec):
     from oracle import icp_oracle
     g = golden("icp_planar.npz")
-    # float32-representable inputs, so that the oracle's device recipe sees the same points
-    src = icp_oracle.as_xyz(g["src"][: g["src_off"][1]]).astype(np.float32).astype(np.float64)
-    tgt = icp_oracle.as_xyz(g["tgt"]).astype(np.float32).astype(np.float64)
-    T, corr, err = icp.icp_iteration(np.hstack((src, np.ones((src.shape[0], 1)))),
-                                     np.hstack((tgt, np.ones((tgt.shape[0], 1)))), icp.TargetCloud(tgt), g["init"][0])
-    To, co, eo = icp_oracle.icp_iteration(src, tgt, g["init"][0], recipe="device", planar=False)
+    src = prec.cast(icp_oracle.as_xyz(g["src"][: g["src_off"][1]]))
+    tgt = prec.cast(icp_oracle.as_xyz(g["tgt"]))
+    T, corr, err = icp.icp_iteration(np.hstack((src, np.ones((src.shape[0], 1), src.dtype))),
+                                     np.hstack((tgt, np.ones((tgt.shape[0], 1), tgt.dtype))), icp.TargetCloud(tgt), g["init"][0])
+    To, co, eo = icp_oracle.icp_iteration(src.astype(np.float64), tgt.astype(np.float64), g["init"][0], recipe=prec.recipe, planar=False)
     np.testing.assert_array_equal(corr, co)
     np.testing.assert_allclose(T, To, atol=1e-10)
     np.testing.assert_allclose(err, eo, rtol=1e-10)
 
 
-def test_errors_match_the_reference(icp):
+def test_errors_match_the_reference(icp, prec):
     g = golden("icp_planar.npz")
-    src = g["src"][:100]
+    src = prec.cast(g["src"][:100])
     with pytest.raises(IndexError):
-        icp.run_icp(src, np.zeros((0, 2)))
+        icp.run_icp(src, np.zeros((0, 2), prec.dtype))
     bad = src.copy(); bad[7, 1] = np.inf
     with pytest.raises(ValueError):
-        icp.run_icp(bad, g["tgt"])
-    T, err, corr = icp.run_icp(np.zeros((0, 2)), g["tgt"], return_error=True, return_correspondences=True)
+        icp.run_icp(bad, prec.cast(g["tgt"]))
+    T, err, corr = icp.run_icp(np.zeros((0, 2), prec.dtype), prec.cast(g["tgt"]), return_error=True, return_correspondences=True)
     assert np.all(np.isnan(T[:3])) and np.array_equal(T[3], [0, 0, 0, 1]) and err == 0.0 and corr.size == 0
 
 
-def test_scan_matching_sequence_vs_golden(icp):
+def test_scan_matching_sequence_vs_golden(icp, prec):
     from lidar_slam_amd.modules.localization import poses_from_scan_matching, scan_matching_relative_poses
     g = golden("seq_scanmatch.npz")
-    z = split(g["z"], g["z_off"])
+    z = [prec.cast(a) for a in split(g["z"], g["z_off"])]
     poses, rel = poses_from_scan_matching(g["x_ts"], z, return_relative_poses=True)
     assert poses.shape == g["poses"].shape and rel.shape == g["relative_poses"].shape
-    assert np.abs(rel[:, :2, 2] - g["relative_poses"][:, :2, 2]).max() < TOL_TRANS
-    assert np.abs(rel[:, :2, :2] - g["relative_poses"][:, :2, :2]).max() < TOL_ROT
-    assert np.abs(poses[:, :2] - g["poses"][:, :2]).max() < 31 * TOL_TRANS
+    assert np.abs(rel[:, :2, 2] - g["relative_poses"][:, :2, 2]).max() < prec.tol_t
+    assert np.abs(rel[:, :2, :2] - g["relative_poses"][:, :2, :2]).max() < prec.tol_r
+    assert np.abs(poses[:, :2] - g["poses"][:, :2]).max() < 31 * prec.tol_t
     _, info = scan_matching_relative_poses(g["x_ts"], z, return_info=True)
     assert int(info.iterations.sum()) == int(g["total_iterations"])
     assert np.array_equal(poses_from_scan_matching(g["x_ts"], z), poses)
@@ -240,11 +279,11 @@ def test_scan_matching_sequence_vs_golden(icp):
 @pytest.mark.parametrize("env", [{"LSLAM_ICP_POINTS_PER_LANE": "1"}, {"LSLAM_ICP_POINTS_PER_LANE": "4"},
                                  {"LSLAM_ICP_TILE_POINTS": "256"}, {"LSLAM_ICP_THREADS": "128"},
                                  {"LSLAM_ICP_TILE_POINTS": "128", "LSLAM_ICP_THREADS": "64", "LSLAM_ICP_POINTS_PER_LANE": "2"}])
-def test_launch_geometry_does_not_change_results(icp, env, monkeypatch):
+def test_launch_geometry_does_not_change_results(icp, env, monkeypatch, prec):
     """register blocking, multi-pass sources and multi-tile targets all give the same answers"""
     from lidar_slam_amd.batch import icp_batch
     g = golden("icp_planar.npz")
-    srcs, flat, off, tgt, toff, init = batch_of(g)
+    srcs, flat, off, tgt, toff, init = batch_of(g, prec)
     base = icp_batch(flat, off, tgt, toff, init, epsilon=0.001, return_correspondences=True)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -254,22 +293,25 @@ def test_launch_geometry_does_not_change_results(icp, env, monkeypatch):
     np.testing.assert_allclose(r.T, base.T, atol=1e-11)
 
 
-def test_large_path_equals_batch_path(icp):
-    """the whole-chip path (one fused or three launches per iteration) and the one-workgroup path agree"""
+@pytest.mark.parametrize("coop", ["1", "0"])
+def test_large_path_equals_batch_path(icp, prec, coop, monkeypatch):
+    """the whole-chip paths (the co-resident one-launch kernel; one fused or three launches per iteration) and the
+    one-workgroup path agree"""
     from lidar_slam_amd import _lib
     from lidar_slam_amd._lib import check, lib, ptr
+    from lidar_slam_amd.batch import icp_batch
+    monkeypatch.setenv("LSLAM_ICP_COOP", coop)
     g = golden("icp_planar.npz")
-    src = np.ascontiguousarray(g["src"][: g["src_off"][1]], dtype=np.float32)
-    tgt = np.ascontiguousarray(g["tgt"], dtype=np.float32)
+    src = prec.cast(g["src"][: g["src_off"][1]])
+    tgt = prec.cast(g["tgt"])
+    entry = lib().lslam_icp_large_f64 if prec.name == "f64" else lib().lslam_icp_large
     for dim, norm in ((2, False), (3, True)):
-        s = src if dim == 2 else np.ascontiguousarray(np.hstack((src, np.zeros((src.shape[0], 1), np.float32))))
-        t = tgt if dim == 2 else np.ascontiguousarray(np.hstack((tgt, np.zeros((tgt.shape[0], 1), np.float32))))
+        s = src if dim == 2 else np.ascontiguousarray(np.hstack((src, np.zeros((src.shape[0], 1), src.dtype))))
+        t = tgt if dim == 2 else np.ascontiguousarray(np.hstack((tgt, np.zeros((tgt.shape[0], 1), tgt.dtype))))
         T = np.empty((4, 4)); err = np.empty(1); it = np.empty(1, np.int32); corr = np.empty(s.shape[0], np.int32)
         T0 = np.ascontiguousarray(g["init"][0])
-        check(lib().lslam_icp_large(ptr(s), s.shape[0], ptr(t), t.shape[0], dim, ptr(T0), 1e-3 if not norm else 1e-7,
-                                    1e-4, 2000, _lib.ICP_NORMALIZE_ERROR if norm else 0, ptr(T), ptr(err), ptr(it),
-                                    ptr(corr), 0))
-        from lidar_slam_amd.batch import icp_batch
+        check(entry(ptr(s), s.shape[0], ptr(t), t.shape[0], dim, ptr(T0), 1e-3 if not norm else 1e-7,
+                    1e-4, 2000, _lib.ICP_NORMALIZE_ERROR if norm else 0, ptr(T), ptr(err), ptr(it), ptr(corr), 0))
         r = icp_batch(s, [0, s.shape[0]], t, [0, t.shape[0]], T0[None], epsilon=1e-3 if not norm else 1e-7,
                       normalize_error=norm, return_correspondences=True)
         assert it[0] == r.iterations[0]
@@ -278,7 +320,7 @@ def test_large_path_equals_batch_path(icp):
         np.testing.assert_allclose(err[0], r.error[0], rtol=1e-9)
 
 
-def test_full_size_batch_properties(icp):
+def test_full_size_batch_properties(icp, prec):
     """BASELINE config sizes (4096 × 4096 planar), checked through size-independent properties:
     a known rigid motion is recovered; results do not depend on which other problems share the launch;
     permuting the target permutes the correspondences and leaves the pose alone."""
@@ -286,6 +328,7 @@ def test_full_size_batch_properties(icp):
     from lidar_slam_amd.synth import batch_c4
     S = 48
     w = batch_c4(S, 4096, seed=123)
+    w.src, w.tgt = prec.cast(w.src), prec.cast(w.tgt)
     r = icp_batch(w.src, w.src_off, w.tgt, w.tgt_off, w.init_T, epsilon=1e-3, return_correspondences=True)
     err_t = np.abs(r.T[:, :2, 3] - w.true_T[:, :2, 3]).max()
     err_R = np.abs(r.T[:, :2, :2] - w.true_T[:, :2, :2]).max()
@@ -303,7 +346,9 @@ def test_full_size_batch_properties(icp):
     np.testing.assert_allclose(pt.T[0], one.T[0], atol=1e-12)
 
 
-def test_dense_3d_nn_against_exact_c_oracle(icp):
+def test_dense_3d_nn_against_exact_c_oracle(icp, prec):
+    if prec.name == "f64":
+        pytest.skip("lslam_nn is the float32 search")
     """100k-style 3-D search (here 20k × 50k so that the CPU oracle finishes in seconds): every index exact"""
     import torch
     from lidar_slam_amd.batch import nn_dev
@@ -334,7 +379,7 @@ def _random_problem(rng, dim, n, m, spread):
 
 
 @pytest.mark.parametrize("dim", [2, 3])
-def test_ragged_random_batch_matches_exact_oracle(icp, dim):
+def test_ragged_random_batch_matches_exact_oracle(icp, dim, prec):
     """ragged sizes from 5 points to a few thousand (rank-deficient toy cases are parity-undefined in the reference), duplicates included: identical iteration
     counts and correspondences as the C oracle's device recipe (exact fmaf), T to 1e-9"""
     from lidar_slam_amd.batch import icp_batch, pack_clouds
@@ -347,12 +392,12 @@ def test_ragged_random_batch_matches_exact_oracle(icp, dim):
         if m > 40:
             t[m // 2] = t[3]                          # an exact duplicate target: lowest index must win
         srcs.append(s); tgts.append(t)
-    fs, so = pack_clouds(srcs)
-    ft, to = pack_clouds(tgts)
+    fs, so = prec.pack(srcs)
+    ft, to = prec.pack(tgts)
     init = np.tile(np.eye(4), (len(sizes), 1, 1))
     r = icp_batch(fs, so, ft, to, init, epsilon=1e-12, max_iters=25, return_correspondences=True)
     for k, (s, t) in enumerate(zip(srcs, tgts)):
-        To, eo, co, ito = c_oracle.run_icp(s, t, np.eye(4), epsilon=1e-12, max_iters=25, recipe="device")
+        To, eo, co, ito = c_oracle.run_icp(s, t, np.eye(4), epsilon=1e-12, max_iters=25, recipe=prec.recipe)
         assert r.iterations[k] == ito, (k, sizes[k])
         np.testing.assert_array_equal(r.correspondences[so[k]:so[k + 1]], co, err_msg=str(sizes[k]))
         np.testing.assert_allclose(r.T[k], To, atol=1e-9, err_msg=str(sizes[k]))
@@ -361,52 +406,57 @@ def test_ragged_random_batch_matches_exact_oracle(icp, dim):
 
 @pytest.mark.parametrize("dim,n,m,fuse", [(2, 700, 5000, 1), (2, 700, 5000, 0), (3, 9000, 3000, 1), (2, 70000, 1200, 1),
                                            (3, 300, 40000, 1), (3, 300, 40000, 0), (2, 8191, 900, 1)])
-def test_whole_chip_path_random_shapes_match_exact_oracle(icp, dim, n, m, fuse, monkeypatch):
-    """the whole-chip path over its geometry regimes (P = 1/2/4, one and many splits; below 8192 source points
-    one fused launch per iteration, or three with LSLAM_ICP_FUSE_TAIL=0)"""
+def test_whole_chip_path_random_shapes_match_exact_oracle(icp, dim, n, m, fuse, monkeypatch, prec):
+    """the whole-chip path over its geometry regimes (P = 1/2/4, one and many splits; below 8192 source points the
+    co-resident one-launch kernel where the target fits its LDS, else one fused launch per iteration, or three with
+    LSLAM_ICP_FUSE_TAIL=0 — which also switches the co-resident kernel off)"""
     from lidar_slam_amd import _lib
     monkeypatch.setenv("LSLAM_ICP_FUSE_TAIL", str(fuse))
+    if not fuse:
+        monkeypatch.setenv("LSLAM_ICP_COOP", "0")
     from lidar_slam_amd._lib import check, lib, ptr
     from oracle import c_oracle
     rng = np.random.default_rng(n + m)
     s, t = _random_problem(rng, dim, n, m, spread=3.0)
-    s32, t32 = np.ascontiguousarray(s, np.float32), np.ascontiguousarray(t, np.float32)
+    sc, tc = prec.cast(s), prec.cast(t)
     T = np.empty((4, 4)); err = np.empty(1); it = np.empty(1, np.int32); corr = np.empty(n, np.int32)
     T0 = np.eye(4)
-    check(lib().lslam_icp_large(ptr(s32), n, ptr(t32), m, dim, ptr(T0), 1e-12, 1e-4, 6, 0, ptr(T), ptr(err), ptr(it), ptr(corr), 0))
-    To, eo, co, ito = c_oracle.run_icp(s, t, np.eye(4), epsilon=1e-12, max_iters=6, recipe="device")
+    entry = lib().lslam_icp_large_f64 if prec.name == "f64" else lib().lslam_icp_large
+    check(entry(ptr(sc), n, ptr(tc), m, dim, ptr(T0), 1e-12, 1e-4, 6, 0, ptr(T), ptr(err), ptr(it), ptr(corr), 0))
+    To, eo, co, ito = c_oracle.run_icp(s, t, np.eye(4), epsilon=1e-12, max_iters=6, recipe=prec.recipe)
     assert it[0] == ito
     np.testing.assert_array_equal(corr, co)
     np.testing.assert_allclose(T, To, atol=1e-9)
     np.testing.assert_allclose(err[0], eo, rtol=1e-9)
 
 
-def test_loop_closure_batch_matches_per_pair_reference_semantics(icp, tmp_path):
+def test_loop_closure_batch_matches_per_pair_reference_semantics(icp, tmp_path, prec):
     """main.py:158-172 as one launch: source = scan i, target = scan i+K, identity init,
     normalize_error=True, default epsilon; gating and file outputs keep the reference's shapes"""
     from lidar_slam_amd.modules.localization import loop_closure_constraints, save_scan_matching_outputs
     from oracle import icp_oracle
     g = golden("seq_scanmatch.npz")
-    z = split(g["z"], g["z_off"])
+    z = [prec.cast(a) for a in split(g["z"], g["z_off"])]
     pairs, T3, errors, ok = loop_closure_constraints(z, fixed_interval=10, max_distance=0.25, max_yaw=2.0)
     assert pairs.tolist() == [[0, 10], [10, 20], [20, 30]]
     for (i, j), T, e in zip(pairs, T3, errors):
-        o = icp_oracle.run_icp_full(z[i], z[j], None, normalize_error=True)          # float64 reference semantics
-        assert np.abs(T[:2, 2] - o.T[:2, 3]).max() < TOL_TRANS and np.abs(T[:2, :2] - o.T[:2, :2]).max() < TOL_ROT
-        assert abs(e - o.error) < 1e-6 * o.error + 1e-12
+        o = icp_oracle.run_icp_full(split(g["z"], g["z_off"])[i], split(g["z"], g["z_off"])[j], None, normalize_error=True)   # float64 reference semantics
+        assert np.abs(T[:2, 2] - o.T[:2, 3]).max() < prec.tol_t and np.abs(T[:2, :2] - o.T[:2, :2]).max() < prec.tol_r
+        assert abs(e - o.error) < prec.err_rtol * o.error + 1e-12
         ang = np.rad2deg(np.arctan2(T[1, 0], T[0, 0]))
         assert ok[list(pairs[:, 0]).index(i)] == (np.linalg.norm(T[:2, 2]) < 0.25 and ang < 2.0)
     paths = save_scan_matching_outputs(g["poses"], g["relative_poses"], 20, out_dir=str(tmp_path))
     assert np.load(paths[0]).shape == (32, 3) and np.load(paths[1]).shape == (31, 3, 3)
 
 
-def test_exact_pruning_gives_the_brute_force_answers(icp):
+def test_exact_pruning_gives_the_brute_force_answers(icp, prec):
     """LSLAM_ICP_PRUNE: Morton-sorted clouds + box tests must not change a single correspondence or
     iteration count (duplicates, ragged sizes, several passes per problem, normalised error)"""
-    from lidar_slam_amd.batch import icp_batch, pack_clouds
+    from lidar_slam_amd.batch import icp_batch
     from lidar_slam_amd.synth import batch_c4
+    pack_clouds = prec.pack
     g = golden("icp_planar.npz")
-    srcs, flat, off, tgt, toff, init = batch_of(g)
+    srcs, flat, off, tgt, toff, init = batch_of(g, prec)
     a = icp_batch(flat, off, tgt, toff, init, epsilon=0.001, return_correspondences=True, prune=False)
     b = icp_batch(flat, off, tgt, toff, init, epsilon=0.001, return_correspondences=True, prune=True)
     np.testing.assert_array_equal(b.iterations, a.iterations)
@@ -433,6 +483,7 @@ def test_exact_pruning_gives_the_brute_force_answers(icp):
         np.testing.assert_allclose(b.T, a.T, atol=1e-10)
 
     w = batch_c4(24, 4096, seed=5)                           # the benchmark's shape
+    w.src, w.tgt = prec.cast(w.src), prec.cast(w.tgt)
     a = icp_batch(w.src, w.src_off, w.tgt, w.tgt_off, w.init_T, epsilon=0.0, stopping_thresh=0.0, max_iters=9, return_correspondences=True, prune=False)
     b = icp_batch(w.src, w.src_off, w.tgt, w.tgt_off, w.init_T, epsilon=0.0, stopping_thresh=0.0, max_iters=9, return_correspondences=True, prune=True)
     np.testing.assert_array_equal(b.correspondences, a.correspondences)
@@ -446,10 +497,11 @@ def test_exact_pruning_gives_the_brute_force_answers(icp):
     np.testing.assert_array_equal(b.T, a.T)
 
 
-def test_pruning_on_degenerate_clouds_with_massive_ties(icp):
+def test_pruning_on_degenerate_clouds_with_massive_ties(icp, prec):
     """lattices, coincident points, a cloud collapsed to one point: every tie must still resolve to the
     lowest ORIGINAL index, exactly as the all-pairs sweep does"""
-    from lidar_slam_amd.batch import icp_batch, pack_clouds
+    from lidar_slam_amd.batch import icp_batch
+    pack_clouds = prec.pack
     rng = np.random.default_rng(5)
     gx, gy = np.meshgrid(np.arange(40) * 0.25, np.arange(40) * 0.25)
     lattice = np.column_stack((gx.ravel(), gy.ravel()))                      # 1600 points, exact ties everywhere
@@ -468,18 +520,21 @@ def test_pruning_on_degenerate_clouds_with_massive_ties(icp):
     b = icp_batch(fs, so, ft, to, I, epsilon=1e-30, max_iters=2, return_correspondences=True, prune=True)
     np.testing.assert_array_equal(b.correspondences, a.correspondences)
     np.testing.assert_array_equal(b.iterations, a.iterations)
-    ok = np.isfinite(a.T).all(axis=(1, 2))
-    np.testing.assert_allclose(b.T[ok], a.T[ok], atol=1e-9)
+    # cases 2 and 3 (a cloud collapsed to one point) have a rank-deficient cross-covariance: rotation undefined
+    defined = [0, 1, 4]
+    assert np.isfinite(a.T[defined]).all() and np.isfinite(b.T[defined]).all()
+    np.testing.assert_allclose(b.T[defined], a.T[defined], atol=1e-9)
     # first iteration of case 0 against a direct evaluation: lowest index among the 4 equidistant corners
-    s32, t32 = (lattice + 0.125).astype(np.float32), shuffled.astype(np.float32)
+    s32, t32 = prec.cast(lattice + 0.125), prec.cast(shuffled)
     one = icp_batch(s32, [0, 1600], t32, [0, 1600], np.eye(4)[None], epsilon=0.0, max_iters=0, stopping_thresh=0.0,
                     return_correspondences=True, prune=True)
     d = ((s32[:, None, :] - t32[None, :, :]) ** 2).sum(-1)
     np.testing.assert_array_equal(one.correspondences, np.argmin(d, axis=1))
 
 
-def test_module_switch_for_pruning_keeps_run_icp_results(icp, monkeypatch):
-    g = golden("icp_3d.npz")
+def test_module_switch_for_pruning_keeps_run_icp_results(icp, monkeypatch, prec):
+    g = {k: (prec.cast(v) if k in ("src", "tgt") else v) for k, v in golden("icp_3d.npz").items()}
+    close_to_reference = prec.close
     monkeypatch.setattr(icp, "PRUNE", False)
     ref = icp.run_icp(g["src"], g["tgt"], g["init"][1], 0.001, return_error=True, normalize_error=True, return_correspondences=True)
     monkeypatch.setattr(icp, "PRUNE", True)
@@ -491,10 +546,11 @@ def test_module_switch_for_pruning_keeps_run_icp_results(icp, monkeypatch):
 
 
 @pytest.mark.parametrize("prune", [False, True])
-def test_sub_range_of_a_packed_buffer(icp, prune):
+def test_sub_range_of_a_packed_buffer(icp, prune, prec):
     """offsets that start in the middle of a larger packed buffer (off[0] > 0): the pruned path keeps its sorted
     copies in batch-local scratch, so a sub-range must give the full batch's answers and touch nothing else"""
-    from lidar_slam_amd.batch import icp_batch, pack_clouds
+    from lidar_slam_amd.batch import icp_batch
+    pack_clouds = prec.pack
     rng = np.random.default_rng(321)
     sizes = [(900, 1100), (4096, 4096), (300, 2000), (1081, 1081), (2000, 64), (64, 3000), (1500, 1500), (700, 4096),
              (4096, 100), (1200, 1000)]
@@ -511,10 +567,10 @@ def test_sub_range_of_a_packed_buffer(icp, prune):
         np.testing.assert_allclose(sub.T, full.T[lo:hi], atol=1e-10)
 
 
-def _oracle_check(r, srcs, tgts, so, init, **kw):
+def _oracle_check(r, srcs, tgts, so, init, recipe, **kw):
     from oracle import c_oracle
     for k, (s, t) in enumerate(zip(srcs, tgts)):
-        To, eo, co, ito = c_oracle.run_icp(s, t, init[k], recipe="device", **kw)
+        To, eo, co, ito = c_oracle.run_icp(s, t, init[k], recipe=recipe, **kw)
         assert r.iterations[k] == ito, k
         np.testing.assert_array_equal(r.correspondences[so[k]:so[k + 1]], co, err_msg=f"problem {k}")
         np.testing.assert_allclose(r.T[k], To, atol=1e-9, err_msg=f"problem {k}")
@@ -522,13 +578,14 @@ def _oracle_check(r, srcs, tgts, so, init, **kw):
 
 @pytest.mark.parametrize("dim", [2, 3])
 @pytest.mark.parametrize("ppl", ["1", "2", "4", "8", "auto"])
-def test_filter_sweep_gives_the_exact_answers(icp, dim, ppl, monkeypatch):
+def test_filter_sweep_gives_the_exact_answers(icp, dim, ppl, monkeypatch, prec):
     """the big build's expanded-form filter (|t|² − 2a·t, then the exact recipe on the chunks within the rounding
     bound) against the C oracle's exact device recipe: random clouds at several scales, duplicates, clouds far from
     the origin (bound too loose: the wave must fall back), tiny and ragged sizes — and against the same build with the filter off"""
-    from lidar_slam_amd.batch import icp_batch, pack_clouds
-    if ppl == "8" and dim == 3:
-        pytest.skip("eight points per lane exist for the planar build only")
+    from lidar_slam_amd.batch import icp_batch
+    pack_clouds = prec.pack
+    if ppl == "8" and (dim == 3 or prec.name == "f64"):
+        pytest.skip("eight points per lane exist for the planar float32 build only")
     monkeypatch.setenv("LSLAM_ICP_VARIANT", "1")            # the big build whatever the size
     if ppl != "auto":                                        # auto: the launcher's own choice (8 for big planar clouds)
         monkeypatch.setenv("LSLAM_ICP_POINTS_PER_LANE", ppl)
@@ -551,7 +608,7 @@ def test_filter_sweep_gives_the_exact_answers(icp, dim, ppl, monkeypatch):
     I = np.tile(np.eye(4), (len(sizes), 1, 1))
     kw = dict(epsilon=1e-12, max_iters=6)
     r = icp_batch(fs, so, ft, to, I, return_correspondences=True, prune=False, **kw)
-    _oracle_check(r, ss, ts, so, I, **kw)
+    _oracle_check(r, ss, ts, so, I, prec.recipe, **kw)
     monkeypatch.setenv("LSLAM_ICP_FILTER", "0")
     e = icp_batch(fs, so, ft, to, I, return_correspondences=True, prune=False, **kw)
     np.testing.assert_array_equal(r.correspondences, e.correspondences)
@@ -559,9 +616,10 @@ def test_filter_sweep_gives_the_exact_answers(icp, dim, ppl, monkeypatch):
     np.testing.assert_allclose(r.T, e.T, rtol=0, atol=0 if ppl != "auto" else 1e-11)   # same pairs and (same P) the same float64 summation order: identical bits
 
 
-def test_filter_sweep_on_lattices_and_collapsed_clouds(icp, monkeypatch):
+def test_filter_sweep_on_lattices_and_collapsed_clouds(icp, monkeypatch, prec):
     """massive ties (every chunk minimum equal): the filter must hand over to the exact sweep, lowest index wins"""
-    from lidar_slam_amd.batch import icp_batch, pack_clouds
+    from lidar_slam_amd.batch import icp_batch
+    pack_clouds = prec.pack
     monkeypatch.setenv("LSLAM_ICP_VARIANT", "1")
     rng = np.random.default_rng(11)
     gx, gy = np.meshgrid(np.arange(60) * 0.25, np.arange(60) * 0.25)
@@ -588,7 +646,7 @@ def test_filter_sweep_on_lattices_and_collapsed_clouds(icp, monkeypatch):
     np.testing.assert_array_equal(a.T, b.T)
     # first iteration of case 0 against a direct evaluation: lowest index among the 4 equidistant corners
     monkeypatch.delenv("LSLAM_ICP_FILTER")
-    s32, t32 = (lattice + 0.125).astype(np.float32), shuffled.astype(np.float32)
+    s32, t32 = prec.cast(lattice + 0.125), prec.cast(shuffled)
     one = icp_batch(s32, [0, 3600], t32, [0, 3600], np.eye(4)[None], epsilon=0.0, max_iters=0, stopping_thresh=0.0, return_correspondences=True, prune=False)
     d = ((s32[:, None, :] - t32[None, :, :]) ** 2).sum(-1)
     np.testing.assert_array_equal(one.correspondences, np.argmin(d, axis=1))
@@ -596,7 +654,7 @@ def test_filter_sweep_on_lattices_and_collapsed_clouds(icp, monkeypatch):
 
 @pytest.mark.parametrize("dim", [2, 3])
 @pytest.mark.parametrize("case", ["duplicates", "lattice", "far", "tiny", "ragged_tail"])
-def test_whole_chip_filter_search_adversarial(icp, case, dim, monkeypatch):
+def test_whole_chip_filter_search_adversarial(icp, case, dim, monkeypatch, prec):
     """the whole-chip search sweeps the expanded form first (nn_tiled_filter_kernel, planar and 3-D): exact duplicates in
     different chunks and splits, lattices (every wave must re-sweep with the exact recipe), a cloud far from the origin
     (bound too loose), sub-millimetre clouds, target counts that leave ragged chunks — all must equal the C oracle's
@@ -617,13 +675,14 @@ def test_whole_chip_filter_search_adversarial(icp, case, dim, monkeypatch):
             t[5000:5040] = t[:40]; t[19000:19040] = t[:40]
         if case == "far":
             s += 3000.0; t += 3000.0
-    s32, t32 = np.ascontiguousarray(s, np.float32), np.ascontiguousarray(t, np.float32)
-    To, eo, co, ito = c_oracle.run_icp(s, t, np.eye(4), epsilon=1e-12, max_iters=3, recipe="device")
+    s32, t32 = prec.cast(s), prec.cast(t)
+    To, eo, co, ito = c_oracle.run_icp(s, t, np.eye(4), epsilon=1e-12, max_iters=3, recipe=prec.recipe)
+    entry = lib().lslam_icp_large_f64 if prec.name == "f64" else lib().lslam_icp_large
     got = {}
     for flt in ("1", "0"):
         monkeypatch.setenv("LSLAM_ICP_FILTER", flt)
         T = np.empty((4, 4)); err = np.empty(1); it = np.empty(1, np.int32); corr = np.empty(s32.shape[0], np.int32)
-        check(lib().lslam_icp_large(ptr(s32), s32.shape[0], ptr(t32), t32.shape[0], dim, ptr(np.eye(4)), 1e-12, 1e-4, 3, 4, ptr(T), ptr(err), ptr(it), ptr(corr), 0))
+        check(entry(ptr(s32), s32.shape[0], ptr(t32), t32.shape[0], dim, ptr(np.eye(4)), 1e-12, 1e-4, 3, 4, ptr(T), ptr(err), ptr(it), ptr(corr), 0))
         assert it[0] == ito
         np.testing.assert_array_equal(corr, co)
         # 3000 m from the origin the float64 moments themselves lose digits to cancellation (order of summation differs)
@@ -633,7 +692,9 @@ def test_whole_chip_filter_search_adversarial(icp, case, dim, monkeypatch):
     np.testing.assert_allclose(got["1"][0], got["0"][0], atol=1e-5 if case == "far" else 1e-12)
 
 
-def test_device_entry_points_on_alternating_streams(icp):
+def test_device_entry_points_on_alternating_streams(icp, prec):
+    if prec.name == "f64":
+        pytest.skip("workspace ordering does not depend on the precision mode")
     """the thread's workspaces (sorted copies, key rows, iteration state) are reused from call to call; calls on different
     streams are ordered by the library (an event per call), so interleaving streams changes nothing"""
     import torch
@@ -679,7 +740,9 @@ def test_device_entry_points_on_alternating_streams(icp):
         np.testing.assert_array_equal(oT.cpu().numpy(), ref[prune])
 
 
-def test_headline_batch_shape_eight_points_per_lane(icp, monkeypatch):
+def test_headline_batch_shape_eight_points_per_lane(icp, monkeypatch, prec):
+    if prec.name == "f64":
+        pytest.skip("the eight-points-per-lane build is the float32 headline kernel")
     """2048 problems of 4096 x 4096 planar points all pairs: the launcher's own choice there is the filter build with
     EIGHT source points per lane in 8-wave workgroups (bench.py's headline kernel).  Sampled problems equal the C oracle's
     exact recipe; the whole batch equals the four-points-per-lane build."""
@@ -706,7 +769,9 @@ def test_headline_batch_shape_eight_points_per_lane(icp, monkeypatch):
 
 
 @pytest.mark.parametrize("strategy", ["filter", "direct", "pruned"])
-def test_full_size_dense_3d_identity_search(icp, strategy, monkeypatch):
+def test_full_size_dense_3d_identity_search(icp, strategy, monkeypatch, prec):
+    if prec.name == "f64":
+        pytest.skip("device-pointer float32 search; the float64-exact whole-chip path has its own full-size test below")
     """BASELINE's 100k x 100k 3-D size through a size-independent property: every point of a cloud is its own nearest
     neighbour in that cloud, at distance exactly 0 — on the filter search, the direct-difference search and the pruned
     search; and one ICP iteration from the identity leaves the identity."""
@@ -736,12 +801,13 @@ def test_full_size_dense_3d_identity_search(icp, strategy, monkeypatch):
     np.testing.assert_allclose(T, np.eye(4), atol=1e-12)
 
 
-def test_exact_pruning_3d_gives_the_brute_force_answers(icp):
+def test_exact_pruning_3d_gives_the_brute_force_answers(icp, prec):
     """the 3-D pruned batch kernel (Morton-sorted float4 copies, 16³ grid, chunk boxes in 3-D): identical correspondences and
     iteration counts as the all-pairs sweep and as the C oracle's exact recipe — ragged sizes up to the kernel's limits
     (4096 targets, 8191 sources), duplicates far apart in index, a lattice with massive ties, a collapsed target,
     normalised error, a sub-range of a packed buffer"""
-    from lidar_slam_amd.batch import icp_batch, pack_clouds
+    from lidar_slam_amd.batch import icp_batch
+    pack_clouds = prec.pack
     from oracle import c_oracle
     rng = np.random.default_rng(333)
     sizes = [(8, 6), (100, 3000), (4096, 4096), (3000, 700), (8191, 64), (513, 4096), (6000, 4000), (1500, 1500)]
@@ -764,12 +830,12 @@ def test_exact_pruning_3d_gives_the_brute_force_answers(icp):
         b = icp_batch(fs, so, ft, to, I, prune=True, **kw)
         np.testing.assert_array_equal(b.iterations, a.iterations)
         np.testing.assert_array_equal(b.correspondences, a.correspondences)
-        ok = np.isfinite(a.T).all(axis=(1, 2))
-        ok[0] = False                                         # 8 sources on 6 targets may match two of them only: rotation not unique
-        np.testing.assert_allclose(b.T[ok], a.T[ok], atol=1e-9)
+        defined = list(range(1, len(ss)))                     # problem 0: 8 sources on 6 targets may match two of them only — rotation not unique
+        assert np.isfinite(a.T[defined]).all() and np.isfinite(b.T[defined]).all()
+        np.testing.assert_allclose(b.T[defined], a.T[defined], atol=1e-9)
     c = icp_batch(fs, so, ft, to, I, prune=True, epsilon=1e-12, max_iters=8, return_correspondences=True)
     for k in (2, 5, 6):
-        To, eo, co, ito = c_oracle.run_icp(ss[k], ts[k], np.eye(4), epsilon=1e-12, max_iters=8, recipe="device")
+        To, eo, co, ito = c_oracle.run_icp(ss[k], ts[k], np.eye(4), epsilon=1e-12, max_iters=8, recipe=prec.recipe)
         assert c.iterations[k] == ito
         np.testing.assert_array_equal(c.correspondences[so[k]:so[k + 1]], co)
         np.testing.assert_allclose(c.T[k], To, atol=1e-9)
