@@ -63,13 +63,15 @@ icp_coop_kernel(CoopArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   TP* tile = reinterpret_cast<TP*>(smem);
   double* tile64 = reinterpret_cast<double*>(smem + a.tile_bytes);                          // F64: the float64 target, DIM doubles per point
-  unsigned long long* skey = reinterpret_cast<unsigned long long*>(smem + a.tile_bytes + a.tile64_bytes);   // [NS][SPW]
+  float4* abox = reinterpret_cast<float4*>(smem + a.tile_bytes + a.tile64_bytes);             // per chunk: {x0, y0, x1, y1} / {lo, hi}
+  unsigned long long* skey = reinterpret_cast<unsigned long long*>(smem + a.tile_bytes + a.tile64_bytes + a.box_bytes);   // [NS][SPW]
   float* ssec = reinterpret_cast<float*>(skey + NS * SPW);                                  // [NS][SPW]
   double* sred = reinterpret_cast<double*>(ssec + NS * SPW);                                // [kVals][65] transposed moments of wave 0
   double* sent = sred + 32 * 65;                                                            // near-tie entries [64][8]: lim, af[3], ad[3], source lane
   unsigned long long* sbest = reinterpret_cast<unsigned long long*>(sent + 64 * 8);         // [64] float64 distance bits of the best candidate
   int* sbj = reinterpret_cast<int*>(sbest + 64);                                            // [64] its index
-  unsigned* rows32 = reinterpret_cast<unsigned*>(sbj + 64);                                 // [G][kVals][2] every workgroup's row
+  int* smatch = sbj + 64;                                                                   // [SPW] last iteration's match of every source (seeds the next search)
+  unsigned* rows32 = reinterpret_cast<unsigned*>(smatch + 64);                              // [G][kVals][2] every workgroup's row
   double* sh_T = reinterpret_cast<double*>(rows32 + (size_t)gridDim.x * kVals * 2);
   double* sh_err = sh_T + 16;
   StopState* sh_stop = reinterpret_cast<StopState*>(sh_err + 1);
@@ -111,11 +113,25 @@ icp_coop_kernel(CoopArgs a) {
     pd[r] = F64 ? (valid ? a.src64[(int64_t)DIM * i + r] : 0.0) : (double)pf[r];
   }
   if (tid < 16) sh_T[tid] = a.state->T[tid];
+  if (tid < SPW) smatch[tid] = (int)(((long long)min(wg * SPW + tid, n - 1) * m) / n);      // first iteration: the target at the same rank (scans are ordered alike)
   if (tid == 0) {
     StopState st0; stop_init(st0); *sh_stop = st0; *sh_err = 0.0;
     sh_flag[0] = 0; sh_flag[1] = 0; sh_flag[2] = 0; sh_flag[3] = 0; sh_flag[4] = 0;
   }
   __syncthreads();
+  // bounding box of every chunk of CH consecutive targets (real points only): consecutive points of a scan are neighbours in
+  // space, so most chunks can be skipped from their box alone (below); clouds in arbitrary order lose nothing but the test
+  for (int c = tid; c < nchunks; c += kCoopThreads) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = 0; k < CH && c * CH + k < m; ++k) {
+      const TP q = tile[c * CH + k];
+      lo[0] = fminf(lo[0], q.x); hi[0] = fmaxf(hi[0], q.x);
+      lo[1] = fminf(lo[1], q.y); hi[1] = fmaxf(hi[1], q.y);
+      if constexpr (DIM == 3) { lo[2] = fminf(lo[2], q.z); hi[2] = fmaxf(hi[2], q.z); }
+    }
+    if constexpr (DIM == 2) abox[c] = make_float4(lo[0], lo[1], hi[0], hi[1]);
+    else { abox[2 * c] = make_float4(lo[0], lo[1], lo[2], 0.f); abox[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f); }
+  }
   float Rt = 0.f, Rs = 0.f;
   if constexpr (F64) {
     float smax = 0.f;
@@ -133,8 +149,9 @@ icp_coop_kernel(CoopArgs a) {
     Rs = sqrtf(__int_as_float(sh_flag[3])) * 1.0001f;
   }
 
-  // my slice of the target: whole chunks [c_lo, c_hi)
-  const int c_lo = (int)(((long long)slice * nchunks) / NS), c_hi = (int)(((long long)(slice + 1) * nchunks) / NS);   // sizes differ by one chunk at most
+  __syncthreads();                                 // boxes (and, in float64-exact mode, the bounds) are in
+  // my slice of the target: chunks slice, slice + NS, … — neighbouring chunks (what the sources of a workgroup typically
+  // need) go to different waves, i.e. different SIMDs
 
   // the rows: [parity][workgroup][value] 16-byte granules {lo32, epoch, hi32, epoch} — each 8-byte half carries its tag
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.gran, 0, (int)a.gran_bytes, 0x00020000);
@@ -167,19 +184,39 @@ icp_coop_kernel(CoopArgs a) {
 
     // ---- search: my source against my slice of the target (exact float32 recipe) ---------------------
     float af[DIM];
+    [[maybe_unused]] double ptf[DIM];                                 // T·p on the float32 point, float64 (what the float32-only mode feeds the moments)
 #pragma unroll
     for (int r = 0; r < DIM; ++r) {                  // icp.py:116
       double v = T[r][0] * (double)pf[0] + T[r][1] * (double)pf[1] + T[r][3];
       if constexpr (DIM == 3) v += T[r][2] * (double)pf[2];
+      ptf[r] = v;
       af[r] = (float)v;
     }
     auto d2 = [&](const float (&p)[DIM], const TP& v) -> float {
       if constexpr (DIM == 2) return dist2(p[0], p[1], v.x, v.y);
       else return dist2(p[0], p[1], p[2], v.x, v.y, v.z);
     };
+    // a bound from last iteration's match (not yet a candidate: its own chunk beats it strictly; in float64-exact mode by
+    // more than the near-tie window, so that the bound is never mistaken for a second candidate) …
+    auto reach = [&](float b) { return F64 ? __builtin_fmaf(b, nt.K1, nt.C) : b; };
+    const float ds = d2(af, tile[smatch[sl]]);
+    const float bound = F64 ? __uint_as_float(__float_as_uint(reach(ds) * 1.000001f) + 1u) : __uint_as_float(__float_as_uint(ds) + 1u);
+    // … lets a chunk be skipped when its box is farther away than everything this lane could still accept
     float best = INFINITY, second = INFINITY;
-    int bchunk = c_lo;
-    for (int c = c_lo; c < c_hi; ++c) {
+    int bchunk = slice;
+    for (int c = slice; c < nchunks; c += NS) {
+      float bd2;
+      if constexpr (DIM == 2) {
+        const float4 b = abox[c];
+        const float ox = fmaxf(fmaxf(b.x - af[0], af[0] - b.z), 0.f), oy = fmaxf(fmaxf(b.y - af[1], af[1] - b.w), 0.f);
+        bd2 = __builtin_fmaf(oy, oy, ox * ox);
+      } else {
+        const float4 lo = abox[2 * c], hi = abox[2 * c + 1];
+        const float ox = fmaxf(fmaxf(lo.x - af[0], af[0] - hi.x), 0.f), oy = fmaxf(fmaxf(lo.y - af[1], af[1] - hi.y), 0.f),
+                    oz = fmaxf(fmaxf(lo.z - af[2], af[2] - hi.z), 0.f);
+        bd2 = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+      }
+      if (!__any(reach(fminf(best, bound)) >= bd2 * 0.99999f)) continue;      // no lane of this wave can find a nearer (or equally near, or near-tie) target here
       float mn = INFINITY;
 #pragma unroll
       for (int k = 0; k < CH; ++k) mn = fminf(mn, d2(af, tile[c * CH + k]));
@@ -190,7 +227,7 @@ icp_coop_kernel(CoopArgs a) {
     }
     unsigned long long key = 0x7f800000ffffffffull;       // an empty slice: distance +inf (all ones would read back as a NaN)
     float sec = second;
-    if (c_lo < c_hi) {
+    if (best < INFINITY) {                                  // this slice evaluated at least one chunk for this lane's wave
       float bd = INFINITY, sec2 = INFINITY;
       int rot = lane;
       asm volatile("" : "+v"(rot));
@@ -289,6 +326,7 @@ icp_coop_kernel(CoopArgs a) {
       }
     }
 
+    if (wave == 0 && sub == 0) smatch[sl] = match;          // read by every wave after the barrier that ends the iteration
     COOP_MARK(2);
     // ---- wave 0: float64 moments of my pairs → transposed reduction → this workgroup's row → all rows → solve ------
     if (wave == 0) {
@@ -297,9 +335,13 @@ icp_coop_kernel(CoopArgs a) {
         double p[DIM], q[DIM];
 #pragma unroll
         for (int r = 0; r < DIM; ++r) {
-          double v = T[r][0] * pd[0] + T[r][1] * pd[1] + T[r][3];
-          if constexpr (DIM == 3) v += T[r][2] * pd[2];
-          p[r] = v;
+          if constexpr (F64) {
+            double v = T[r][0] * pd[0] + T[r][1] * pd[1] + T[r][3];
+            if constexpr (DIM == 3) v += T[r][2] * pd[2];
+            p[r] = v;
+          } else {
+            p[r] = ptf[r];
+          }
         }
         if constexpr (F64) {
 #pragma unroll
@@ -371,12 +413,31 @@ icp_coop_kernel(CoopArgs a) {
       failed = __any(failed);
       COOP_MARK(5);
       // totals in workgroup order (every workgroup: the same bits)
+      // totals: lane (value v, quarter qr) folds workgroups qr, qr + 4, … in that order, then the quarters are folded — a fixed
+      // order, the same in every workgroup (bit-identical totals), a quarter of the dependent chain
       double col = 0.0;
-      if (lane < nvals) {
-        for (int w = 0; w < G; ++w) {
-          const unsigned lo = rows32[(w * kVals + lane) * 2], hi = rows32[(w * kVals + lane) * 2 + 1];
-          const double v = __hiloint2double((int)hi, (int)lo);
-          col = (w == 0) ? v : ((lane < kSums) ? col + v : ((lane < kSums + DIM) ? fmin(col, v) : fmax(col, v)));
+      {
+        const int cv = lane & 15, qr = lane >> 4;
+        if (cv < nvals || VP == 32) {
+          for (int half = 0; half < (VP == 32 ? 2 : 1); ++half) {          // 3-D rows have up to 22 values: lanes take v and v + 16
+            const int v = cv + 16 * half;
+            if (v >= nvals) continue;
+            double acc = 0.0;
+            bool first = true;
+            for (int w = qr; w < G; w += 4) {
+              const unsigned lo = rows32[(w * kVals + v) * 2], hi = rows32[(w * kVals + v) * 2 + 1];
+              const double x = __hiloint2double((int)hi, (int)lo);
+              acc = first ? x : ((v < kSums) ? acc + x : ((v < kSums + DIM) ? fmin(acc, x) : fmax(acc, x)));
+              first = false;
+            }
+            // fold the four quarters (lanes cv, cv + 16, cv + 32, cv + 48); a quarter without a workgroup holds the neutral element
+            if (first) acc = (v < kSums) ? 0.0 : ((v < kSums + DIM) ? INFINITY : -INFINITY);
+            sred[(v * 4 + qr)] = acc;
+          }
+        }
+        if (lane < nvals) {
+          const double q0 = sred[lane * 4], q1 = sred[lane * 4 + 1], q2 = sred[lane * 4 + 2], q3 = sred[lane * 4 + 3];
+          col = (lane < kSums) ? ((q0 + q1) + (q2 + q3)) : ((lane < kSums + DIM) ? fmin(fmin(q0, q1), fmin(q2, q3)) : fmax(fmax(q0, q1), fmax(q2, q3)));
         }
       }
       Moments mo;
@@ -469,8 +530,9 @@ hipError_t launch_icp_coop(CoopArgs a, int dim, hipStream_t stream) {
   a.tile_bytes = (uint32_t)(((size_t)padded * (dim == 2 ? 8 : 16) + 15) & ~(size_t)15);
   a.tile64_bytes = f64 ? (uint32_t)(((size_t)a.m * dim * 8 + 15) & ~(size_t)15) : 0u;
   a.gran_bytes = (uint32_t)icp_coop_gran_bytes(dim, a.n);
+  a.box_bytes = (uint32_t)((size_t)(padded / CH) * (dim == 2 ? 16 : 32));
   const size_t slots = (size_t)kCoopWaves * 64;                  // NS·SPW
-  const size_t smem = a.tile_bytes + a.tile64_bytes + slots * (8 + 4) + (32 * 65 + 64 * 8) * 8 + 64 * (8 + 4) + (size_t)G * kVals * 2 * 4 +
+  const size_t smem = a.tile_bytes + a.tile64_bytes + a.box_bytes + 64 * 4 + slots * (8 + 4) + (32 * 65 + 64 * 8) * 8 + 64 * (8 + 4) + (size_t)G * kVals * 2 * 4 +
                       17 * 8 + sizeof(StopState) + 32;
   // every polled word starts at zero (epochs count from 1 within the launch)
   hipError_t e = hipMemsetAsync(a.gran, 0, a.gran_bytes, stream);

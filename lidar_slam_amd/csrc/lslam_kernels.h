@@ -193,7 +193,7 @@ struct CoopArgs {
   uint32_t flags;
   double epsilon, stopping_thresh;
   int32_t max_iters;
-  uint32_t tile_bytes, tile64_bytes, gran_bytes;   // filled by the launcher
+  uint32_t tile_bytes, tile64_bytes, box_bytes, gran_bytes;   // filled by the launcher
 };
 bool icp_coop_supported(int dim, int64_t n, int64_t m, bool f64);
 size_t icp_coop_gran_bytes(int dim, int64_t n);
