@@ -28,33 +28,44 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_VECTOR_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CUs × 4 SIMD × 32 lanes × 2 flop × 2.4 GHz
 PEAK_HBM_TBS = 8.0
-HEADLINE_KERNEL = "icp_batch_filter_kernel<2,8>"      # what launch_icp_batch picks for 4096 problems of 4096 planar points
+HEADLINE_KERNEL = "icp_batch_filter_kernel<2,8,false>"      # what launch_icp_batch picks for 4096 problems of 4096 planar points
 
 
 def headline_kernel(S, P):
     """the build launch_icp_batch (csrc/lslam_icp_batch.hip) picks for S all-pairs problems of P planar points"""
     if P <= 2560:
-        return "icp_batch_small_kernel<2,*>"
+        return "icp_batch_small_kernel<2,*,false>"
     if P > 8192:
-        return "icp_batch_kernel<2,4>"
-    return HEADLINE_KERNEL if (P >= 3584 and S >= 2048) else "icp_batch_filter_kernel<2,4>"
+        return "icp_batch_kernel<2,4,false>"
+    return HEADLINE_KERNEL if (P >= 3584 and S >= 2048) else "icp_batch_filter_kernel<2,4,false>"
 
 
-def profile_figures(workload, kernel):
+def profile_figures(workload, kernel, root=None, current_hash=None):
     """Figures that only a PMC pass can give (HBM bytes per launch, VALU instructions per pair evaluation), read from the
-    newest committed profiles/rNN/pmc_traffic.json and used ONLY if that file was taken on the kernel this run
-    launches — a stale entry (another kernel name) is not reported."""
+    newest committed profiles/rNN/pmc_traffic.json — and reported ONLY if that file was taken on the very sources this
+    run's library was built from (sha256 over lidar_slam_amd/csrc, stored by tools/profile_round.sh) and on the kernel this
+    run launches.  Anything else comes back as {"stale_profile": why}: no counter of another kernel body is ever printed."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
-        try:
-            e = json.load(open(f))[workload]
-        except Exception:
-            continue
-        if e.get("kernel") == kernel:
-            return {"hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "lane_ops_per_pair_eval": e.get("lane_ops_per_pair_eval"),
-                    "source": os.path.relpath(f, ROOT)}
-        return {}
-    return {}
+    root = root or ROOT
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*", "pmc_traffic.json")), reverse=True)
+    if not files:
+        return {"stale_profile": "no committed PMC profile"}
+    f = files[0]
+    try:
+        doc = json.load(open(f))
+        e = doc[workload]
+    except Exception:
+        return {"stale_profile": f"{os.path.relpath(f, root)} has no entry for {workload}"}
+    if current_hash is None:
+        from lidar_slam_amd._lib import csrc_hash
+        current_hash = csrc_hash()
+    if doc.get("csrc_sha256") != current_hash:
+        return {"stale_profile": f"{os.path.relpath(f, root)} was taken on other kernel sources (csrc hash differs): re-run tools/profile_round.sh"}
+    if e.get("kernel") != kernel:
+        return {"stale_profile": f"{os.path.relpath(f, root)} profiles {e.get('kernel')}, this run launches {kernel}"}
+    return {"hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "lane_ops_per_pair_eval": e.get("lane_ops_per_pair_eval"),
+            "issue_utilisation": e.get("valu_instruction_issue_utilisation_at_2_cycles_per_wave64"),
+            "source": os.path.relpath(f, root)}
 
 
 def parse():
@@ -314,18 +325,20 @@ def main():
         probe = ctypes.c_double(0.0)
         check(lib().lslam_valu_probe(local_rank, ctypes.byref(probe)))
         issue_rate = probe.value                                   # lane-ops/s this device sustains under an all-VALU load
-        prof = profile_figures("c4", HEADLINE_KERNEL)
+        # counters exist for the default shape only, and only while the committed profile matches these sources and this kernel
+        prof = profile_figures("c4", headline_kernel(S, P)) if (S, P, I) == (4096, 4096, 50) else {"stale_profile": "counters are profiled for 4096 x 4096 x 50 only"}
         result = {
             "metric": "icp_iterations_per_sec", "value": total_iters / dt, "unit": "iterations/s",
             "n_gpus": dist.get_world_size() if use_dist else 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C4 synthetic batch: {S} scan pairs per GPU x {P}x{P} planar points, {I} forced ICP iterations per pair",
-                       "pairs_per_gpu": S, "points": P, "iterations": I, "sharding": f"independent pairs over {world} GPU(s), all-gather of poses", "search": "all pairs (LSLAM_ICP_ALL_PAIRS)"},
+                       "pairs_per_gpu": S, "points": P, "iterations": I, "sharding": f"independent pairs over {world} GPU(s), all-gather of poses", "search": "all pairs (LSLAM_ICP_ALL_PAIRS)",
+                       "precision": "float32 points in HBM (lslam_icp_batch_dev); the float64-exact mode is timed beside it (float64_exact_mode)"},
             "scan_pairs_per_sec": world * S * a.steps / dt,
             "pair_evals_per_sec": world * pair_evals_per_launch * a.steps / dt,
             "roofline": {"kernel": headline_kernel(S, P), "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
-                         "traffic": prof.get("hbm_bytes_per_launch") if (S, P, I) == (4096, 4096, 50) else None,
+                         "traffic": prof.get("hbm_bytes_per_launch"), "stale_profile": prof.get("stale_profile"),
                          "kernel_ms": kernel_ms, "algorithmic_flop_per_pair_eval": 5,
                          "pair_evals_per_s": pair_evals_per_launch / (kernel_ms * 1e-3),
                          "device_valu_probe_lane_ops_per_s": issue_rate,
@@ -336,7 +349,7 @@ def main():
             # the same launch priced against the HBM roof, as the bench contract words it (algorithmic bytes / duration): four orders away, not the binding roof
             "roofline_hbm": {"kernel": headline_kernel(S, P), "bound": "hbm", "achieved": (2 * S * P * 8 + S * 2 * 128) / (kernel_ms * 1e-3) / 1e9,
                              "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": (2 * S * P * 8 + S * 2 * 128) / (kernel_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
-                             "traffic": prof.get("hbm_bytes_per_launch") if (S, P, I) == (4096, 4096, 50) else None,
+                             "traffic": prof.get("hbm_bytes_per_launch"),
                              "measured_GBps": (prof.get("hbm_bytes_per_launch") or 0) / (kernel_ms * 1e-3) / 1e9 if prof.get("hbm_bytes_per_launch") else None,
                              "measured_frac": (prof.get("hbm_bytes_per_launch") or 0) / (kernel_ms * 1e-3) / 1e12 / PEAK_HBM_TBS if prof.get("hbm_bytes_per_launch") else None,
                              "note": "algorithmic bytes = both clouds once + transforms in/out per problem, independent of the iteration count; measured_* = PMC traffic of the committed profile over this run's kernel time"},
@@ -359,6 +372,25 @@ def main():
                                                  "ms_per_step": ms_p, "icp_iterations_per_sec": S * I / (ms_p * 1e-3),
                                                  "speedup_vs_all_pairs_sweep": (dt / a.steps * 1e3) / ms_p,
                                                  "max_abs_T_difference": float((oT2 - out_T).abs().max().item())}
+        if rank == 0 and world == 1:
+            # float64-exact mode (what run_icp / poses_from_scan_matching use): the same clouds also resident in float64; near
+            # ties of the float32 search decided on them, moments from them — results equal to the reference's float64 search
+            src64, tgt64 = src.to(torch.float64), tgt.to(torch.float64)
+            oT4 = torch.empty_like(out_T)
+            def step_f64(prune):
+                B.icp_batch_dev(src.data_ptr(), off.data_ptr(), tgt.data_ptr(), off.data_ptr(), 2, init.data_ptr(), S, P, P,
+                                oT4.data_ptr(), out_err.data_ptr(), out_it.data_ptr(), None, epsilon=0.0, max_iters=I - 1,
+                                stopping_thresh=0.0, stream=stream, prune=prune, d_src64=src64.data_ptr(), d_tgt64=tgt64.data_ptr())
+            ms_f64_default = _time(torch, lambda: step_f64(None), 1, max(2, a.steps // 2))
+            d_default = float((oT4 - oT2).abs().max().item())
+            ms_f64_all = _time(torch, lambda: step_f64(False), 1, 2)
+            result["float64_exact_mode"] = {"what": "same workload with the float64 clouds beside the float32 ones (lslam_icp_batch_dev64): correspondences of a float64 search, moments from the float64 points",
+                                            "ms_per_step_default_strategy": ms_f64_default, "ms_per_step_all_pairs": ms_f64_all,
+                                            "cost_vs_float32_default_strategy": ms_f64_default / result["default_search_strategy"]["ms_per_step"],
+                                            "cost_vs_float32_all_pairs": ms_f64_all / (dt / a.steps * 1e3),
+                                            "max_abs_T_difference_to_float32_mode": d_default,
+                                            "note": "the synthetic clouds are float32-representable, so both modes see the same points; the difference is the float32 recipe's rounding of near ties"}
+            del src64, tgt64
         if rank == 0 and world == 1 and a.natural:
             # the same batch left to the reference's own stop rules (scan-matching call: epsilon 1e-3, defaults else).
             # Opt-in: it launches the headline kernel with a tenth of the work, which would blur that kernel's
@@ -525,20 +557,30 @@ def other_config(name, a, torch, device, stream, timed):
                             stopping_thresh=0.0, stream=stream, prune=False)
         ms = _time(torch, run, 3, 20)
         res = {}
-        def run_chip():
+        s64, t64 = s.to(torch.float64), t.to(torch.float64)
+        def run_chip(f64=False, coop=True):
+            os.environ["LSLAM_ICP_COOP"] = "1" if coop else "0"
             res["r"] = B.icp_large_dev(s.data_ptr(), 1081, t.data_ptr(), 1081, 2, np.eye(4), epsilon=0.0, max_iters=a.iters - 1,
-                                       stopping_thresh=0.0, poll_every=a.iters, stream=stream, prune=False)
+                                       stopping_thresh=0.0, poll_every=a.iters, stream=stream, prune=False,
+                                       d_src64=s64.data_ptr() if f64 else None, d_tgt64=t64.data_ptr() if f64 else None)
         ms_chip = _time(torch, run_chip, 3, 20)
+        T_chip = res["r"][0].copy()
+        ms_chip64 = _time(torch, lambda: run_chip(True), 3, 20)
+        ms_launches = _time(torch, lambda: run_chip(False, False), 3, 20)
+        os.environ.pop("LSLAM_ICP_COOP", None)
         out = {"workload": "C2 single planar pair 1081x1081, 50 forced iterations", "ms_one_workgroup": ms, "ms_whole_chip": ms_chip,
+               "ms_whole_chip_float64_exact": ms_chip64, "ms_one_launch_per_iteration": ms_launches,
                "ms": min(ms, ms_chip), "iterations_per_sec": a.iters / (min(ms, ms_chip) * 1e-3),
-               "pose_err_vs_truth": float(np.abs(res["r"][0] - T_true).max()),
-               "paths_agree": float(np.abs(res["r"][0] - oT[0].cpu().numpy()).max()),
-               "roofline": {"kernel": "nn_tiled_kernel<2,1,true> (search + fused key reduction, moments, solve: one launch per iteration)",
-                            "bound": "launch latency", "us_per_iteration": ms_chip * 1e3 / a.iters,
+               "pose_err_vs_truth": float(np.abs(T_chip - T_true).max()),
+               "paths_agree": float(np.abs(T_chip - oT[0].cpu().numpy()).max()),
+               "roofline": {"kernel": "icp_coop_kernel<2,1,false>: ONE launch for the whole run, 17 co-resident workgroups (64 sources each, whole target in LDS), "
+                                      "per iteration one all-gather of 9 float64 moments per workgroup through tagged 16-byte granules",
+                            "bound": "cross-CU hand-off latency + one-wave float64 tail", "us_per_iteration": ms_chip * 1e3 / a.iters,
+                            "us_per_iteration_float64_exact": ms_chip64 * 1e3 / a.iters, "us_per_iteration_one_launch_each": ms_launches * 1e3 / a.iters,
                             "achieved": a.iters * 1081.0 * 1081 * 5 / (ms_chip * 1e-3) / 1e12, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                             "frac": a.iters * 1081.0 * 1081 * 5 / (ms_chip * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
-                            "note": "1.17 M pair evaluations per iteration are 0.1 us of chip time; an iteration is one dependent kernel launch "
-                                    "(about 6 us of dispatch + the serial solve of the last workgroup)"}}
+                            "note": "1.17 M pair evaluations per iteration are 0.1 us of chip time; an iteration is: box-pruned sweep 1.4 us, "
+                                    "moments 1.0, granule all-gather 2.2, solve 1.1 (tools/c2_phases.py); includes ~25 us per call of upload / memset / read-back"}}
     elif name == "c5":
         src, tgt, T_true, T0 = synth.cloud_c5()
         s = torch.from_numpy(src).to(device); t = torch.from_numpy(tgt).to(device)
@@ -562,14 +604,27 @@ def other_config(name, a, torch, device, stream, timed):
                "default_search_strategy": {"what": "same 20 iterations, strategy left to the library (pruning above 1e9 pair evaluations per iteration: Morton sort + box hierarchy, exact results; the sort is inside the timed call)",
                           "ms": ms_p, "speedup": ms / ms_p, "max_abs_T_difference": float(np.abs(res["p"][0] - T).max())},
                "pose_err_vs_truth": float(np.abs(T - T_true).max())}
+        s64, t64 = s.to(torch.float64), t.to(torch.float64)
+        def run64():
+            res["d"] = B.icp_large_dev(s.data_ptr(), s.shape[0], t.data_ptr(), t.shape[0], 3, T0, epsilon=0.0, max_iters=19,
+                                       stopping_thresh=0.0, poll_every=20, stream=stream, d_src64=s64.data_ptr(), d_tgt64=t64.data_ptr())
+        ms64 = _time(torch, run64, 1, 3)
+        out["float64_exact_mode"] = {"what": "same 20 iterations in float64-exact mode (all pairs: the pruned whole-chip search has no float64 refinement)",
+                                     "ms": ms64, "cost_vs_float32_all_pairs": ms64 / ms, "max_abs_T_difference": float(np.abs(res["d"][0] - T).max())}
     elif name == "c3":
         from lidar_slam_amd.modules.localization import scan_matching_relative_poses, chain_poses
         seq, gen_s = _sequence()
         scan_matching_relative_poses(seq.x_ts[:64], seq.z_ts[:64])                     # warm-up
+        _warm_gpu()
         t0 = time.perf_counter()
-        rel, info = scan_matching_relative_poses(seq.x_ts, seq.z_ts, return_info=True)
+        rel, info = scan_matching_relative_poses(seq.x_ts, seq.z_ts, return_info=True)       # float64 scans: float64-exact mode
         poses = chain_poses(rel)
         stage_s = time.perf_counter() - t0
+        z32 = [z.astype(np.float32) for z in seq.z_ts]
+        scan_matching_relative_poses(seq.x_ts[:64], z32[:64])
+        t0 = time.perf_counter()
+        rel32, info32 = scan_matching_relative_poses(seq.x_ts, z32, return_info=True)        # float32 scans: float32 search only
+        stage32_s = time.perf_counter() - t0
         # CPU baseline on a bounded sample of the same sequence (oracle KDTree port = reference algorithm)
         from oracle import se2_oracle
         n = 400
@@ -578,7 +633,9 @@ def other_config(name, a, torch, device, stream, timed):
         cpu_s = time.perf_counter() - t0
         same = int(np.sum(info.iterations[:n] == it_cpu))
         out = {"workload": "C3 dataset-20-like sequence: 4955 consecutive scan pairs (650-1081 pts), natural convergence, host arrays in/out (PCIe + chain included)",
-               "stage_seconds": stage_s, "scan_pairs_per_sec": 4955 / stage_s, "total_iterations": int(info.iterations.sum()),
+               "stage_seconds": stage_s, "stage_seconds_float32_scans": stage32_s, "iteration_counts_differ_float32_vs_float64_exact": int(np.sum(info.iterations != info32.iterations)),
+               "max_rel_pose_difference_float32_vs_float64_exact": float(np.abs(rel - rel32).max()),
+               "scan_pairs_per_sec": 4955 / stage_s, "total_iterations": int(info.iterations.sum()),
                "cpu_port_seconds_per_pair": cpu_s / n, "cpu_port_extrapolated_seconds": cpu_s / n * 4955,
                "speedup_vs_cpu_port_1core": (cpu_s / n * 4955) / stage_s, "iteration_counts_equal_on_sample": f"{same}/{n}",
                "synth_seconds": gen_s, "final_pose": poses[-1].tolist()}

@@ -121,6 +121,23 @@ def lib():
     return _lib
 
 
+def csrc_hash() -> str:
+    """sha256 over the library's sources (csrc/*.hip, csrc/*.h, include/lslam.h, the Makefile) in name order: identifies
+    the kernels a profile was taken on (tools/profile_round.sh stores it beside the counters; bench.py reports
+    profile-derived figures only while it still matches)."""
+    import glob
+    import hashlib
+    root = os.path.dirname(_HERE)
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   [os.path.join(_HERE, "csrc", "Makefile"), os.path.join(root, "include", "lslam.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def last_error() -> str:
     return lib().lslam_last_error().decode("utf-8", "replace")
 

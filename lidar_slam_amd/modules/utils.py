@@ -9,11 +9,13 @@ import numpy as np
 def transform_points(points, T):
     """Apply a 4×4 transform to (N,3) points or a 3×3 transform to (N,2) points
     (modules/utils.py:140-159); any other combination raises ValueError."""
-    if T.shape == (4, 4) and points.shape[1] == 3:
-        return points @ T[:3, :3].T + T[:3, 3]
-    if T.shape == (3, 3) and points.shape[1] == 2:
-        return points @ T[:2, :2].T + T[:2, 2]
-    raise ValueError("Invalid point or transformation matrix shape.")
+    d = {(4, 4): 3, (3, 3): 2}.get(T.shape)
+    if d is None or points.shape[1] != d:
+        raise ValueError("Invalid point or transformation matrix shape.")
+    # the homogeneous product itself, as the reference forms it: the translation enters the same dot product
+    # as the rotation (p·Rᵀ + t would round differently)
+    homogeneous = np.concatenate((points, np.ones((points.shape[0], 1))), axis=1)
+    return (T @ homogeneous.T).T[:, :d]
 
 
 def T_from_pose(pose):

@@ -84,3 +84,32 @@ def test_spawned_ranks_get_a_launcher_environment_and_rank0_line_is_relayed(tmp_
                           f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.__file__ = {str(prog)!r}; "
                           "sys.exit(bench.spawn_ranks(3, []))"], capture_output=True, text=True, timeout=120, env={**os.environ, "FAIL_RANK": "2"})
     assert bad.returncode != 0 and bad.stdout.strip() == "" and "rank 2" in bad.stderr
+
+
+def test_profile_derived_fields_are_reported_only_for_the_sources_they_were_taken_on(tmp_path):
+    """roofline.traffic / instruction counts come from a committed PMC profile: they must vanish (with a reason) as soon as
+    the kernel sources differ from the profiled ones, or another kernel is launched"""
+    import json
+    import bench
+    d = tmp_path / "profiles" / "r09"
+    d.mkdir(parents=True)
+    doc = {"csrc_sha256": "abc", "c4": {"kernel": "K<2,8,false>", "hbm_bytes_per_launch": 123.0, "lane_ops_per_pair_eval": 3.0}}
+    (d / "pmc_traffic.json").write_text(json.dumps(doc))
+    ok = bench.profile_figures("c4", "K<2,8,false>", root=str(tmp_path), current_hash="abc")
+    assert ok["hbm_bytes_per_launch"] == 123.0 and ok["lane_ops_per_pair_eval"] == 3.0 and "stale_profile" not in ok
+    stale = bench.profile_figures("c4", "K<2,8,false>", root=str(tmp_path), current_hash="other")
+    assert "stale_profile" in stale and "hbm_bytes_per_launch" not in stale
+    wrong_kernel = bench.profile_figures("c4", "K<2,4,false>", root=str(tmp_path), current_hash="abc")
+    assert "stale_profile" in wrong_kernel and "hbm_bytes_per_launch" not in wrong_kernel
+    assert "stale_profile" in bench.profile_figures("c4", "K", root=str(tmp_path / "nothing"), current_hash="abc")
+    # a newer round without the hash (or without the entry) never lets an older one through
+    d2 = tmp_path / "profiles" / "r10"
+    d2.mkdir()
+    (d2 / "pmc_traffic.json").write_text(json.dumps({"c4": doc["c4"]}))
+    assert "stale_profile" in bench.profile_figures("c4", "K<2,8,false>", root=str(tmp_path), current_hash="abc")
+
+
+def test_csrc_hash_follows_the_sources(tmp_path):
+    from lidar_slam_amd._lib import csrc_hash
+    h = csrc_hash()
+    assert len(h) == 64 and h == csrc_hash()

@@ -842,3 +842,61 @@ def test_exact_pruning_3d_gives_the_brute_force_answers(icp, prec):
     sub = icp_batch(fs, so[5:8], ft, to[5:8], I[5:7], prune=True, epsilon=1e-12, max_iters=8, return_correspondences=True)
     np.testing.assert_array_equal(sub.correspondences[so[5]:so[7]], c.correspondences[so[5]:so[7]])
     np.testing.assert_allclose(sub.T, c.T[5:7], atol=1e-10)
+
+
+_C3 = {}
+
+
+def _c3_sequence():
+    """the dataset-20-like sequence of BASELINE configs[2], generated once per session"""
+    if "seq" not in _C3:
+        from lidar_slam_amd.synth import sequence_c3
+        _C3["seq"] = sequence_c3(4956, seed=20)
+    return _C3["seq"]
+
+
+def test_full_size_c3_sequence_vs_oracle(icp, prec):
+    """BASELINE configs[2] at FULL size: 4956 scans (4955 ragged pairs, 650-1081 points) through poses_from_scan_matching —
+    one launch.  400 pairs spread over the sequence are re-run by the C oracle: identical iteration counts, relative poses
+    within 1e-9 of the oracle's; the chain of all 4955 relative poses equals the oracle's sequential float64 chain."""
+    from lidar_slam_amd.modules.localization import (chain_poses, poses_from_scan_matching, relative_pose_guesses,
+                                                     scan_matching_relative_poses)
+    from oracle import c_oracle, se2_oracle
+    seq = _c3_sequence()
+    z = [prec.cast(a) for a in seq.z_ts]
+    rel, info = scan_matching_relative_poses(seq.x_ts, z, return_info=True)
+    assert rel.shape == (4955, 3, 3) and info.iterations.shape == (4955,) and info.iterations.min() >= 1
+    init = relative_pose_guesses(seq.x_ts)
+    sample = np.linspace(0, 4954, 400).astype(int)
+    for k in sample:
+        To, eo, co, ito = c_oracle.run_icp(seq.z_ts[k + 1], seq.z_ts[k], init[k], epsilon=0.001, recipe=prec.recipe)
+        assert info.iterations[k] == ito, k
+        assert np.abs(rel[k][:2, :2] - To[:2, :2]).max() < 1e-9 and np.abs(rel[k][:2, 2] - To[:2, 3]).max() < 1e-9, k
+        assert abs(info.error[k] - eo) < 1e-9 * max(1.0, eo)
+    poses = poses_from_scan_matching(seq.x_ts, z)
+    np.testing.assert_array_equal(poses, chain_poses(rel))
+    np.testing.assert_allclose(poses, se2_oracle.chain_relative_poses(rel), atol=1e-9)
+
+
+def test_full_size_c4_batch_vs_oracle(icp, prec):
+    """BASELINE configs[3] at FULL size: 4096 pairs x 4096 x 4096 points in one launch (the library's default search
+    strategy, reference stop rules).  Three sampled problems equal the C oracle (iterations, every correspondence, T);
+    the batch recovers the generating motions; the all-pairs strategy gives the same iteration counts for every pair."""
+    from lidar_slam_amd.batch import icp_batch
+    from lidar_slam_amd.synth import batch_c4
+    from oracle import c_oracle
+    S = 4096
+    w = batch_c4(S, 4096, seed=11)
+    src, tgt = prec.cast(w.src), prec.cast(w.tgt)
+    r = icp_batch(src, w.src_off, tgt, w.tgt_off, w.init_T, epsilon=1e-3, return_correspondences=True)
+    assert r.iterations.shape == (S,) and r.iterations.min() >= 1
+    for k in (0, 1777, S - 1):
+        sl = slice(k * 4096, (k + 1) * 4096)
+        To, eo, co, ito = c_oracle.run_icp(w.src[sl].astype(np.float64), w.tgt[sl].astype(np.float64), w.init_T[k], epsilon=1e-3, recipe=prec.recipe)
+        assert r.iterations[k] == ito
+        np.testing.assert_array_equal(r.correspondences[sl], co)
+        np.testing.assert_allclose(r.T[k], To, atol=1e-9)
+    assert np.abs(r.T[:, :2, 3] - w.true_T[:, :2, 3]).max() < 2e-3            # 1 cm noise on 4096 points
+    a = icp_batch(src, w.src_off, tgt, w.tgt_off, w.init_T, epsilon=1e-3, prune=False)
+    np.testing.assert_array_equal(a.iterations, r.iterations)
+    np.testing.assert_allclose(a.T, r.T, atol=1e-10)

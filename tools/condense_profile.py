@@ -50,7 +50,7 @@ out = {}
 fetch, _ = counters("pmc_fetch")
 write, _ = counters("pmc_write")
 sq, dur = counters("pmc_sq")
-for tag, needle in (("c4", "icp_batch_filter_kernel<2, 8>"), ("c4_default_search_strategy", "icp_pruned_kernel<1>"), ("c4_sort", "icp_sort_kernel")):
+for tag, needle in (("c4", "icp_batch_filter_kernel<2, 8, false>"), ("c4_default_search_strategy", "icp_pruned_kernel<1, false>"), ("c4_float64_exact", "icp_pruned_kernel<1, true>"), ("c4_sort", "icp_sort_kernel")):
     kf, kw, ks = pick(fetch, needle), pick(write, needle), pick(sq, needle)
     if not (kf and kw and ks):
         continue
@@ -76,8 +76,11 @@ if "c4" in out:
         if key in bench:
             bench[key]["traffic"] = out["c4"]["hbm_bytes_per_launch"]
     bench["roofline"]["kernel_valu_instructions_per_pair_eval"] = out["c4"]["lane_ops_per_pair_eval"]
+    bench["roofline"].pop("stale_profile", None)
     bench["roofline"]["profile"] = os.path.join("profiles", dst, "pmc_traffic.json")
     open(os.path.join(O, "bench_default_n1.json"), "w").write(json.dumps(bench, indent=1) + "\n")
+# bench.py reports these figures only while the library is still built from the sources they were taken on
+out["csrc_sha256"] = open(os.path.join(I, "csrc_sha256.txt")).read().strip()
 out["command"] = "tools/profile_round.sh: rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs (one counter group per pass: FETCH_SIZE | WRITE_SIZE | SQ_*, GRBM_GUI_ACTIVE)"
 json.dump(out, open(os.path.join(O, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])

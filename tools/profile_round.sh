@@ -7,6 +7,7 @@ R=${1:-r02}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python3 -c "from lidar_slam_amd._lib import csrc_hash; print(csrc_hash())" > $OUT/csrc_sha256.txt || exit 9   # the sources these counters belong to
 python3 bench.py > $OUT/bench_default_n1.json 2> $OUT/bench_default_n1.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 2
 B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs"
