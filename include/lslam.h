@@ -49,6 +49,11 @@ int         lslam_device_count(void);
 /* bind the calling host thread to a device (one host thread / process per GPU) */
 int         lslam_set_device(int device);
 
+/* Pinned host memory owned by the library, one buffer per (calling thread, slot 0|1), grown on demand and valid until
+ * the same thread asks for the same slot again.  Packing a scan list into it before lslam_icp_batch* / lslam_ogm_update
+ * makes the upload one DMA at PCIe speed (no reference counterpart: the reference never leaves the host). */
+int         lslam_host_staging(int slot, size_t bytes, void **out_ptr);
+
 /* Measurement aid (no reference counterpart): the float32 VALU issue rate this device sustains
  * under an all-VALU load, in lane-operations per second (≈ 10 ms of v_fma_f32 on every SIMD). */
 int         lslam_valu_probe(int device, double *out_lane_ops_per_s);
@@ -91,6 +96,9 @@ int         lslam_valu_probe(int device, double *out_lane_ops_per_s);
  * The environment variable LSLAM_ICP_PRUNE (0 / 1) changes that default; an explicit bit wins over it. */
 #define LSLAM_ICP_PRUNE 2u       /* force pruning (ignored where unsupported) */
 #define LSLAM_ICP_ALL_PAIRS 4u   /* force the all-pairs sweep */
+/* host entry points only: the caller has already verified that every coordinate is finite (e.g. while packing the
+ * scans), so the library skips its own pass over the points.  Non-finite points under this flag are undefined. */
+#define LSLAM_ICP_INPUT_CHECKED 8u
 
 int lslam_icp_batch(const float *src, const int64_t *src_off,
                     const float *tgt, const int64_t *tgt_off,

@@ -12,6 +12,7 @@ OK, ERR_BAD_ARG, ERR_EMPTY_TARGET, ERR_NONFINITE, ERR_HIP = 0, -1, -2, -3, -4
 ICP_NORMALIZE_ERROR = 1
 ICP_PRUNE = 2
 ICP_ALL_PAIRS = 4
+ICP_INPUT_CHECKED = 8
 
 
 def search_flags(prune):
@@ -39,6 +40,7 @@ SIGNATURES = {
     "lslam_device_count": (C.c_int, []),
     "lslam_set_device": (C.c_int, [C.c_int]),
     "lslam_valu_probe": (C.c_int, [C.c_int, C.c_void_p]),
+    "lslam_host_staging": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
     "lslam_icp_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_uint32, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
@@ -136,6 +138,36 @@ def csrc_hash() -> str:
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+_pyhost = None
+
+
+def pyhost():
+    """the CPython packing helper (csrc/pyhost/lslam_pyhost.cpp), or None when it is not built (NumPy packs then)"""
+    global _pyhost
+    if _pyhost is None:
+        path = os.path.join(_HERE, "lib", "_lslam_pyhost.so")
+        _pyhost = False
+        if os.path.exists(path):
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("_lslam_pyhost", path)
+            try:
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                _pyhost = mod
+            except Exception:
+                _pyhost = False
+    return _pyhost or None
+
+
+def staging_array(slot, count, dtype):
+    """numpy view of ``count`` elements of the thread's pinned staging buffer ``slot`` (valid until the slot is asked for again)"""
+    import numpy as np
+    nbytes = max(int(count), 1) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    check(lib().lslam_host_staging(int(slot), nbytes, C.byref(p)))
+    return np.frombuffer((C.c_char * nbytes).from_address(p.value), dtype=dtype, count=int(count))
 
 
 def last_error() -> str:

@@ -57,10 +57,69 @@ for _name in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "e
     setattr(PackedScans, _name, _invalidating(_name))
 
 
-def pack_clouds(clouds, dtype=np.float64):
+_STAGED_POINTS = {}          # (slot, dim, dtype) -> points the thread's pinned staging slot is known to hold
+
+
+class StagedClouds(np.ndarray):
+    """a packed cloud array living in the library's pinned staging buffer; ``.checked`` = every coordinate was seen finite
+    while packing (the library then skips its own pass: LSLAM_ICP_INPUT_CHECKED)"""
+    checked = False
+
+
+def _pack_staged(clouds, dtype, slot):
+    """list of arrays -> pinned staging buffer, in C with a few threads (csrc/pyhost); None when the helper cannot take
+    this list (not built, an element that is not a C-contiguous float array, …)"""
+    import os
+    ph = _lib.pyhost()
+    if ph is None or not isinstance(clouds, list) or not len(clouds) or isinstance(clouds, PackedScans):
+        return None
+    first = clouds[0]
+    if not isinstance(first, np.ndarray) or first.ndim != 2 or first.shape[1] not in (2, 3):
+        return None
+    d = first.shape[1]
+    want = dtype or (np.float32 if first.dtype == np.float32 else np.float64)
+    off = np.empty(len(clouds) + 1, dtype=np.int64)
+    threads = min(16, os.cpu_count() or 1)
+    for _ in range(3):
+        key = (slot, d, np.dtype(want).name)
+        cap = _STAGED_POINTS.get(key, 0)
+        arr = _lib.staging_array(slot, max(cap, 1) * d, want)
+        r = ph.pack_list(clouds, arr.ctypes.data, cap, d, int(want == np.float64), off.ctypes.data, threads)
+        if r is None:
+            return None
+        total, finite, n_f64 = r
+        if dtype is None and want == np.float32 and n_f64:          # a float64 scan among float32 ones: keep the precision
+            want = np.float64
+            continue
+        if finite == -1:                                             # first time at this size: grow the slot and pack again
+            _STAGED_POINTS.clear()                                   # (the slot is shared by all shapes: forget what it held)
+            _STAGED_POINTS[key] = total + total // 8 + 1024
+            continue
+        if finite == 0:
+            raise ValueError("point clouds must be finite (NaN or Inf found)")
+        flat = arr[: total * d].reshape(total, d).view(StagedClouds)
+        flat.checked = True
+        return flat, off
+    return None
+
+
+def pack_clouds(clouds, dtype=None, staging=None):
     """list of (n_i, d) arrays -> (``dtype`` (Σn_i, d) C-contiguous, int64 offsets (len+1,)).
-    float64 (the default) keeps the points as the reference has them — ``icp_batch`` then runs in float64-exact mode;
-    float32 rounds them in the same pass (half the upload, float32-exact search)."""
+    ``dtype=None`` keeps the points as they are handed over: float32 if EVERY cloud is float32 (``icp_batch`` then searches
+    them as they are), float64 otherwise — the reference's own type; ``icp_batch`` then runs in float64-exact mode.
+    An explicit float32 rounds float64 clouds in the same pass (half the upload, float32-exact search).
+    ``staging=0|1``: pack into that pinned staging slot of the library with the C helper (several threads, finiteness
+    checked on the way, upload at PCIe speed) — the result is only valid until the slot is used again, so this is for
+    callers that hand it to the library at once."""
+    if staging is not None:
+        staged = _pack_staged(clouds, dtype, staging)
+        if staged is not None:
+            return staged
+    if dtype is None:
+        if isinstance(clouds, PackedScans) and clouds.packed() is not None:
+            dtype = np.float32 if clouds.packed()[0].dtype == np.float32 else np.float64
+        else:
+            dtype = np.float32 if (len(clouds) and all(getattr(c, "dtype", None) == np.float32 for c in clouds)) else np.float64
     if isinstance(clouds, PackedScans):
         packed = clouds.packed()
         if packed is not None:
@@ -92,6 +151,7 @@ def icp_batch(src, src_off, tgt, tgt_off, init_T, epsilon=0.01, max_iters=2000, 
     that provably cannot hold a nearer point skipped), False = the all-pairs sweep.  Same correspondences and
     iteration counts either way."""
     same = tgt is src
+    checked = bool(getattr(src, "checked", False)) and bool(getattr(tgt, "checked", False))     # packed by the C helper: finiteness already seen
     src = np.asarray(src)
     dtype = np.float32 if (src.dtype == np.float32 and np.asarray(tgt).dtype == np.float32) else np.float64
     src = np.ascontiguousarray(src, dtype=dtype)
@@ -110,7 +170,7 @@ def icp_batch(src, src_off, tgt, tgt_off, init_T, epsilon=0.01, max_iters=2000, 
     out_err = np.empty(S, dtype=np.float64)
     out_it = np.empty(S, dtype=np.int32)
     corr = np.empty(int(src_off[-1]) if S else 0, dtype=np.int32) if return_correspondences else None
-    flags = (_lib.ICP_NORMALIZE_ERROR if normalize_error else 0) | _lib.search_flags(prune)
+    flags = (_lib.ICP_NORMALIZE_ERROR if normalize_error else 0) | _lib.search_flags(prune) | (_lib.ICP_INPUT_CHECKED if checked else 0)
     entry = lib().lslam_icp_batch_f64 if dtype == np.float64 else lib().lslam_icp_batch
     check(entry(ptr(src), ptr(src_off), ptr(tgt), ptr(tgt_off), src.shape[1], ptr(init_T), S,
                 float(epsilon), float(stopping_thresh), int(max_iters), flags,

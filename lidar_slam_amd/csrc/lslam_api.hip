@@ -156,6 +156,24 @@ int lslam_set_device(int device) {
   return use_device(device);
 }
 
+// Pinned host staging buffers of the calling thread (two slots): packing a scan list straight into one makes the upload
+// that follows a single DMA at PCIe speed instead of a staged copy from pageable memory.
+int lslam_host_staging(int slot, size_t bytes, void** out_ptr) {
+  clear_error();
+  if (!out_ptr || slot < 0 || slot > 1) return fail(LSLAM_ERR_BAD_ARG, "slot must be 0 or 1 and out_ptr non-null");
+  static thread_local void* buf[2] = {nullptr, nullptr};
+  static thread_local size_t cap[2] = {0, 0};
+  if (bytes > cap[slot]) {
+    if (buf[slot]) { LSLAM_HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(buf[slot]); }
+    buf[slot] = nullptr; cap[slot] = 0;
+    const size_t want = bytes + (bytes >> 2) + (1u << 20);
+    LSLAM_HIP_TRY(hipHostMalloc(&buf[slot], want, hipHostMallocDefault));
+    cap[slot] = want;
+  }
+  *out_ptr = buf[slot];
+  return LSLAM_OK;
+}
+
 int lslam_valu_probe(int device, double* out_lane_ops_per_s) {
   clear_error();
   if (!out_lane_ops_per_s) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
@@ -296,9 +314,11 @@ static int icp_batch_host(const PT* src, const int64_t* src_off, const PT* tgt, 
   if ((rc = check_offsets(tgt_off, S, "tgt_off", &max_m, &tot_m)) != LSLAM_OK) return rc;
   for (int32_t s = 0; s < S; ++s)
     if (tgt_off[s + 1] == tgt_off[s]) return fail(LSLAM_ERR_EMPTY_TARGET, "problem %d has an empty target cloud", s);
-  bool finite;
-  if constexpr (kF64) finite = all_finite64(src + dim * src_off[0], dim * (tot_n - src_off[0])) && all_finite64(tgt + dim * tgt_off[0], dim * (tot_m - tgt_off[0]));
-  else finite = all_finite(src + dim * src_off[0], dim * (tot_n - src_off[0])) && all_finite(tgt + dim * tgt_off[0], dim * (tot_m - tgt_off[0]));
+  bool finite = true;
+  if (!(flags & LSLAM_ICP_INPUT_CHECKED)) {                // the caller has not vouched for the points
+    if constexpr (kF64) finite = all_finite64(src + dim * src_off[0], dim * (tot_n - src_off[0])) && all_finite64(tgt + dim * tgt_off[0], dim * (tot_m - tgt_off[0]));
+    else finite = all_finite(src + dim * src_off[0], dim * (tot_n - src_off[0])) && all_finite(tgt + dim * tgt_off[0], dim * (tot_m - tgt_off[0]));
+  }
   if (!finite) return fail(LSLAM_ERR_NONFINITE, "point clouds must be finite (NaN or Inf found)");
   if (dim == 2)                                           // the planar kernels never materialise z
     for (int32_t s = 0; s < S; ++s) {
@@ -334,23 +354,60 @@ static int icp_batch_host(const PT* src, const int64_t* src_off, const PT* tgt, 
 
   hipStream_t st;
   if ((rc = thread_stream(&st)) != LSLAM_OK) return rc;
-  if constexpr (kF64) {
-    LSLAM_HIP_TRY(hipMemcpyAsync(d_src64, src, b_src64, hipMemcpyHostToDevice, st));
-    LSLAM_HIP_TRY(launch_f64_to_f32(d_src64, d_src, (int64_t)n_src, st));
-    if (!shared) {
-      LSLAM_HIP_TRY(hipMemcpyAsync(d_tgt64, tgt, b_tgt64, hipMemcpyHostToDevice, st));
-      LSLAM_HIP_TRY(launch_f64_to_f32(d_tgt64, d_tgt, (int64_t)n_tgt, st));
-    }
-  } else {
-    LSLAM_HIP_TRY(hipMemcpyAsync(d_src, src, b_src, hipMemcpyHostToDevice, st));
-    if (!shared) LSLAM_HIP_TRY(hipMemcpyAsync(d_tgt, tgt, b_tgt, hipMemcpyHostToDevice, st));
-  }
   LSLAM_HIP_TRY(hipMemcpyAsync(d_so, src_off, b_off, hipMemcpyHostToDevice, st));
   LSLAM_HIP_TRY(hipMemcpyAsync(d_to, tgt_off, b_off, hipMemcpyHostToDevice, st));
   LSLAM_HIP_TRY(hipMemcpyAsync(d_iT, init_T, b_T, hipMemcpyHostToDevice, st));
-  rc = lslam_icp_batch_dev64(d_src, d_src64, d_so, d_tgt, d_tgt64, d_to, dim, d_iT, S, max_n, max_m, epsilon, stopping_thresh,
-                             max_iters, flags, d_oT, d_err, d_it, d_corr, st);
-  if (rc != LSLAM_OK) return rc;
+  // upload [lo, hi) points of one cloud array (and round it to float32 on the device in float64-exact mode)
+  auto upload = [&](const PT* host, float* d32, double* d64, int64_t lo, int64_t hi, hipStream_t cs) -> int {
+    if (hi <= lo) return LSLAM_OK;
+    const size_t at = (size_t)dim * (size_t)lo, cnt = (size_t)dim * (size_t)(hi - lo);
+    if constexpr (kF64) {
+      LSLAM_HIP_TRY(hipMemcpyAsync(d64 + at, reinterpret_cast<const double*>(host) + at, sizeof(double) * cnt, hipMemcpyHostToDevice, cs));
+      LSLAM_HIP_TRY(launch_f64_to_f32(d64 + at, d32 + at, (int64_t)cnt, cs));
+    } else {
+      LSLAM_HIP_TRY(hipMemcpyAsync(d32 + at, reinterpret_cast<const float*>(host) + at, sizeof(float) * cnt, hipMemcpyHostToDevice, cs));
+    }
+    return LSLAM_OK;
+  };
+  // Big batches are pipelined: the problems go in kChunks launches, and while one runs the points of the next are on
+  // their way over PCIe (a second stream + one event per chunk).  Problems are independent (modules/localization.py:116-123),
+  // so the results do not depend on the split.  (Offsets grow with the problem index: check_offsets above.)
+  constexpr int kChunks = 4;
+  const bool pipelined = S >= 4 * kChunks && (b_src + b_tgt + b_src64 + b_tgt64) >= (size_t)(8u << 20) && !getenv("LSLAM_NO_UPLOAD_PIPELINE");
+  if (!pipelined) {
+    if ((rc = upload(src, d_src, d_src64, 0, up_src, st)) != LSLAM_OK) return rc;
+    if (!shared && (rc = upload(tgt, d_tgt, d_tgt64, 0, tot_m, st)) != LSLAM_OK) return rc;
+    rc = lslam_icp_batch_dev64(d_src, d_src64, d_so, d_tgt, d_tgt64, d_to, dim, d_iT, S, max_n, max_m, epsilon, stopping_thresh,
+                               max_iters, flags, d_oT, d_err, d_it, d_corr, st);
+    if (rc != LSLAM_OK) return rc;
+  } else {
+    static thread_local hipStream_t copy_stream = nullptr;
+    static thread_local hipEvent_t landed[kChunks] = {};
+    static thread_local int cs_dev = -1;
+    if (!copy_stream || cs_dev != device) {
+      LSLAM_HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+      for (int c = 0; c < kChunks; ++c) LSLAM_HIP_TRY(hipEventCreateWithFlags(&landed[c], hipEventDisableTiming));
+      cs_dev = device;
+    }
+    // the copy stream starts after everything this thread queued before (the arena may still be read by an earlier call)
+    LSLAM_HIP_TRY(hipEventRecord(landed[0], st));
+    LSLAM_HIP_TRY(hipStreamWaitEvent(copy_stream, landed[0], 0));
+    int64_t up_s = shared ? std::min(src_off[0], tgt_off[0]) : src_off[0], up_t = tgt_off[0];      // uploaded so far (points)
+    int32_t s0 = 0;
+    for (int c = 0; c < kChunks; ++c) {
+      const int32_t s1 = (c + 1 == kChunks) ? S : (int32_t)((int64_t)S * (c + 1) / kChunks);
+      const int64_t need_s = shared ? std::max(src_off[s1], tgt_off[s1]) : src_off[s1], need_t = tgt_off[s1];
+      if ((rc = upload(src, d_src, d_src64, up_s, need_s, copy_stream)) != LSLAM_OK) return rc;
+      up_s = std::max(up_s, need_s);
+      if (!shared) { if ((rc = upload(tgt, d_tgt, d_tgt64, up_t, need_t, copy_stream)) != LSLAM_OK) return rc; up_t = std::max(up_t, need_t); }
+      LSLAM_HIP_TRY(hipEventRecord(landed[c], copy_stream));
+      LSLAM_HIP_TRY(hipStreamWaitEvent(st, landed[c], 0));
+      rc = lslam_icp_batch_dev64(d_src, d_src64, d_so + s0, d_tgt, d_tgt64, d_to + s0, dim, d_iT + 16 * (size_t)s0, s1 - s0, max_n, max_m, epsilon,
+                                 stopping_thresh, max_iters, flags, d_oT + 16 * (size_t)s0, d_err + s0, d_it + s0, d_corr, st);
+      if (rc != LSLAM_OK) return rc;
+      s0 = s1;
+    }
+  }
   LSLAM_HIP_TRY(hipMemcpyAsync(out_T, d_oT, b_T, hipMemcpyDeviceToHost, st));
   LSLAM_HIP_TRY(hipMemcpyAsync(out_err, d_err, sizeof(double) * S, hipMemcpyDeviceToHost, st));
   LSLAM_HIP_TRY(hipMemcpyAsync(out_iters, d_it, sizeof(int32_t) * S, hipMemcpyDeviceToHost, st));
@@ -1018,6 +1075,8 @@ struct Ogm {
   OgmGrid g{};
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;                  // uploads of a long trajectory, one chunk ahead of the kernels
+  hipEvent_t landed = nullptr;
   double* d_scan = nullptr; int64_t scan_cap = 0;     // points
   int4* d_rays = nullptr; int64_t rays_cap = 0;       // one record per ray of the current call
   int4* d_batch = nullptr;                            // one box per 64 rays of a scan (rays_cap / 64 + desc_cap of them)
@@ -1185,6 +1244,8 @@ int lslam_ogm_destroy(void* handle) {
   Ogm* o = static_cast<Ogm*>(handle);
   (void)hipSetDevice(o->device);
   if (o->stream) (void)hipStreamSynchronize(o->stream);
+  if (o->copy_stream) { (void)hipStreamSynchronize(o->copy_stream); (void)hipStreamDestroy(o->copy_stream); }
+  if (o->landed) (void)hipEventDestroy(o->landed);
   if (o->g.logodds) (void)hipFree(o->g.logodds);
   if (o->g.steps) (void)hipFree(o->g.steps);
   if (o->d_values) (void)hipFree(o->d_values);
@@ -1229,25 +1290,34 @@ static int ogm_planes(Ogm* o, int planes) {
 // Upload one descriptor per scan; one launch turns every ray into a record and every scan into a touched
 // box; then per group of up to kOgmPlanes scans: tile launch → apply (or nothing) launch.  No host
 // synchronisation inside.
-static int ogm_enqueue(Ogm* o, const double* poses, const double* d_points, const int64_t* scan_off,
-                       int64_t first_point, int32_t K, bool apply) {
-  if (K <= 0) return LSLAM_OK;
-  const int64_t total = scan_off[K] - first_point;
-  int rc_planes = ogm_planes(o, K < kOgmPlanes ? K : kOgmPlanes);     // update_map needs one plane, build_map a full group
-  if (rc_planes != LSLAM_OK) return rc_planes;
+// descriptors / boxes for K scans, ray records (and 64-ray batch boxes) for `total` rays
+static int ogm_reserve(Ogm* o, int64_t K, int64_t total) {
   if (K > o->desc_cap || total > o->rays_cap) {
+    LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));          // earlier work may still use the old buffers
     if (o->d_desc) (void)hipFree(o->d_desc);
     if (o->d_boxes) (void)hipFree(o->d_boxes);
     if (o->d_rays) (void)hipFree(o->d_rays);
     if (o->d_batch) (void)hipFree(o->d_batch);
-    o->d_desc = nullptr; o->d_boxes = nullptr; o->d_rays = nullptr; o->d_batch = nullptr; o->desc_cap = 0; o->rays_cap = 0;
-    const int64_t want_k = K + K / 4 + 64, want_r = total + total / 4 + 1024;
+    o->d_desc = nullptr; o->d_boxes = nullptr; o->d_rays = nullptr; o->d_batch = nullptr;
+    const int64_t k_now = K > o->desc_cap ? K : o->desc_cap, r_now = total > o->rays_cap ? total : o->rays_cap;
+    o->desc_cap = 0; o->rays_cap = 0;
+    const int64_t want_k = k_now + k_now / 4 + 64, want_r = r_now + r_now / 4 + 1024;
     LSLAM_HIP_TRY(hipMalloc(&o->d_desc, sizeof(OgmScan) * (size_t)want_k));
     LSLAM_HIP_TRY(hipMalloc(&o->d_boxes, sizeof(int) * 4 * (size_t)want_k));
     LSLAM_HIP_TRY(hipMalloc(&o->d_rays, sizeof(int4) * (size_t)want_r));
     LSLAM_HIP_TRY(hipMalloc(&o->d_batch, sizeof(int4) * (size_t)(want_r / 64 + want_k + 1)));
     o->desc_cap = want_k; o->rays_cap = want_r;
   }
+  return LSLAM_OK;
+}
+
+static int ogm_enqueue(Ogm* o, const double* poses, const double* d_points, const int64_t* scan_off,
+                       int64_t first_point, int32_t K, bool apply) {
+  if (K <= 0) return LSLAM_OK;
+  const int64_t total = scan_off[K] - first_point;
+  int rc_planes = ogm_planes(o, K < kOgmPlanes ? K : kOgmPlanes);     // update_map needs one plane, build_map a full group
+  if (rc_planes != LSLAM_OK) return rc_planes;
+  { const int rc_res = ogm_reserve(o, K, total); if (rc_res != LSLAM_OK) return rc_res; }
   o->h_desc.resize((size_t)K);
   int max_rays = 0;
   for (int32_t k = 0; k < K; ++k) {
@@ -1298,12 +1368,45 @@ int lslam_ogm_update(void* handle, const double* poses, const double* scans_xy, 
   const int64_t first = scan_off[0], total = scan_off[K] - first;
   int rc;
   if ((rc = ogm_scan_buffer(o, total)) != LSLAM_OK) return rc;
-  if (total > 0) {
-    if (!scans_xy) return fail(LSLAM_ERR_BAD_ARG, "null scan pointer");
-    LSLAM_HIP_TRY(hipMemcpyAsync(o->d_scan, scans_xy + 2 * first, sizeof(double) * 2 * (size_t)total, hipMemcpyHostToDevice, o->stream));
+  if (total > 0 && !scans_xy) return fail(LSLAM_ERR_BAD_ARG, "null scan pointer");
+  // A long trajectory goes in chunks of scans: while one chunk is traced and applied (scan order is kept: chunks and
+  // the groups inside them run in order on the grid's stream), the points of the next are on their way over PCIe on a
+  // second stream.  Same cells, same order, same result as one piece.
+  constexpr int32_t kChunk = 8 * kOgmPlanes;                 // 1024 scans
+  if (K <= kChunk || total * 16 < (8 << 20) || getenv("LSLAM_NO_UPLOAD_PIPELINE")) {
+    if (total > 0) LSLAM_HIP_TRY(hipMemcpyAsync(o->d_scan, scans_xy + 2 * first, sizeof(double) * 2 * (size_t)total, hipMemcpyHostToDevice, o->stream));
+    if ((rc = ogm_enqueue(o, poses, o->d_scan, scan_off, first, K, true)) != LSLAM_OK) return rc;
+    LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+    return LSLAM_OK;
   }
-  if ((rc = ogm_enqueue(o, poses, o->d_scan, scan_off, first, K, true)) != LSLAM_OK) return rc;
-  LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+  if (!o->copy_stream) {
+    LSLAM_HIP_TRY(hipStreamCreateWithFlags(&o->copy_stream, hipStreamNonBlocking));
+    LSLAM_HIP_TRY(hipEventCreateWithFlags(&o->landed, hipEventDisableTiming));
+  }
+  if ((rc = ogm_reserve(o, K, total)) != LSLAM_OK) return rc;           // once, for the whole trajectory (chunks index into it)
+  LSLAM_HIP_TRY(hipEventRecord(o->landed, o->stream));       // the copies start after whatever still reads d_scan
+  LSLAM_HIP_TRY(hipStreamWaitEvent(o->copy_stream, o->landed, 0));
+  // every chunk's copy is queued up front (they run back to back on the copy stream), each followed by its own event
+  const int32_t nchunks = (K + kChunk - 1) / kChunk;
+  std::vector<hipEvent_t> ev((size_t)nchunks);
+  for (int32_t c = 0; c < nchunks; ++c) {
+    const int32_t k0 = c * kChunk, k1 = std::min(K, k0 + kChunk);
+    const int64_t p0 = scan_off[k0] - first, p1 = scan_off[k1] - first;
+    if (p1 > p0) LSLAM_HIP_TRY(hipMemcpyAsync(o->d_scan + 2 * p0, scans_xy + 2 * (first + p0), sizeof(double) * 2 * (size_t)(p1 - p0), hipMemcpyHostToDevice, o->copy_stream));
+    LSLAM_HIP_TRY(hipEventCreateWithFlags(&ev[(size_t)c], hipEventDisableTiming));
+    LSLAM_HIP_TRY(hipEventRecord(ev[(size_t)c], o->copy_stream));
+  }
+  rc = LSLAM_OK;
+  for (int32_t c = 0; c < nchunks && rc == LSLAM_OK; ++c) {
+    const int32_t k0 = c * kChunk, k1 = std::min(K, k0 + kChunk);
+    if (hipStreamWaitEvent(o->stream, ev[(size_t)c], 0) != hipSuccess) { rc = fail(LSLAM_ERR_HIP, "hipStreamWaitEvent failed"); break; }
+    rc = ogm_enqueue(o, poses + 3 * (size_t)k0, o->d_scan, scan_off + k0, first, k1 - k0, true);
+  }
+  const hipError_t e = hipStreamSynchronize(o->stream);
+  (void)hipStreamSynchronize(o->copy_stream);
+  for (auto& x : ev) (void)hipEventDestroy(x);
+  if (rc != LSLAM_OK) return rc;
+  LSLAM_HIP_TRY(e);
   return LSLAM_OK;
 }
 

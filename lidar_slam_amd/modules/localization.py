@@ -56,7 +56,9 @@ def scan_matching_relative_poses(x_ts, z_ts, device=0, return_info=False):
         rel[:, :2, :2] = r.T[:, :2, :2]
         rel[:, :2, 2] = r.T[:, :2, 3]
         return (rel, r) if return_info else rel
-    pts, off = pack_clouds(z_ts if isinstance(z_ts, PackedScans) else [np.asarray(z) for z in z_ts])
+    # a plain list of scans is packed straight into the library's pinned staging buffer by the C helper (a few threads,
+    # finiteness checked on the way); an already packed list is used as it is
+    pts, off = pack_clouds(z_ts if isinstance(z_ts, (PackedScans, list)) else [np.asarray(z) for z in z_ts], staging=0)
     if pts.shape[1] != 2:
         raise ValueError("scans must be (n_i, 2) robot-frame points")
     # source = scan i, target = scan i-1 (localization.py:120-121)
@@ -84,8 +86,8 @@ def loop_closure_constraints(z_ts, n_poses=None, fixed_interval=10, max_distance
     starts = np.arange(0, n_poses - K, K, dtype=np.int64)
     if starts.size == 0:
         return np.zeros((0, 2), np.int64), np.zeros((0, 3, 3)), np.zeros(0), np.zeros(0, bool)
-    src, so = pack_clouds([np.asarray(z_ts[i]) for i in starts])
-    tgt, to = pack_clouds([np.asarray(z_ts[i + K]) for i in starts])
+    src, so = pack_clouds([np.asarray(z_ts[i]) for i in starts], staging=0)
+    tgt, to = pack_clouds([np.asarray(z_ts[i + K]) for i in starts], staging=1)
     r = icp_batch(src, so, tgt, to, np.tile(np.eye(4), (starts.size, 1, 1)), normalize_error=True, device=device)
     T3 = np.tile(np.eye(3), (starts.size, 1, 1))
     T3[:, :2, :2] = r.T[:, :2, :2]

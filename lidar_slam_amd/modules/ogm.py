@@ -98,10 +98,22 @@ class OccupancyGridMap:
         if packed is not None and packed[0].dtype == np.float64 and packed[0].ndim == 2 and packed[0].shape[1] == 2:
             flat, off = np.ascontiguousarray(packed[0]), packed[1]        # already packed: no copies
         else:
-            off = np.zeros(K + 1, dtype=np.int64)
-            scans = [np.asarray(meas[i], dtype=np.float64).reshape(-1, 2) for i in range(K)]
-            off[1:] = np.cumsum([s.shape[0] for s in scans])
-            flat = np.ascontiguousarray(np.concatenate(scans, axis=0)) if K else np.zeros((0, 2))
+            staged = None
+            if isinstance(meas, list) and len(meas) == K and K:
+                # a plain list of (n_i, 2) arrays: packed by the C helper (a few threads) straight into the library's pinned
+                # staging buffer, from where the upload is one DMA; anything it cannot take is packed with NumPy below
+                from ..batch import _pack_staged
+                try:
+                    staged = _pack_staged(meas, np.float64, 0)
+                except ValueError:
+                    staged = None                                 # non-finite points: the reference does not check here either
+            if staged is not None:
+                flat, off = staged
+            else:
+                off = np.zeros(K + 1, dtype=np.int64)
+                scans = [np.asarray(meas[i], dtype=np.float64).reshape(-1, 2) for i in range(K)]
+                off[1:] = np.cumsum([s.shape[0] for s in scans])
+                flat = np.ascontiguousarray(np.concatenate(scans, axis=0)) if K else np.zeros((0, 2))
         check(lib().lslam_ogm_update(self._handle, ptr(states), ptr(flat), ptr(off), K))
         self._host_stale = True
         out = np.empty(self._shape, dtype=np.uint8)
