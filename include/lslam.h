@@ -111,7 +111,13 @@ int lslam_icp_batch(const float *src, const int64_t *src_off,
 /* Same, all pointers on the device; max_src_n / max_tgt_n bound the per-problem
  * sizes (they fix the launch geometry; the offsets are only read on the device).
  * Inputs are trusted to be finite and every target non-empty (the host entry
- * point validates; this one cannot without a synchronisation). */
+ * point validates; this one cannot without a synchronisation).
+ * Enqueues on `stream` and returns — with two exceptions a caller overlapping streams must know: (1) the pruned
+ * kernels keep Morton-sorted copies in a workspace of the calling thread; the first call at a larger size (more
+ * problems x points) re-allocates it behind a hipDeviceSynchronize(), and a call on a different stream than the
+ * thread's previous workspace-using call waits (on the device) for that call; (2) the all-pairs sweep
+ * (LSLAM_ICP_ALL_PAIRS, or the automatic choice for small clouds) uses no workspace and is never ordered or
+ * synchronised by the library.  Not capturable into a hipGraph while a workspace may still grow. */
 int lslam_icp_batch_dev(const float *d_src, const int64_t *d_src_off,
                         const float *d_tgt, const int64_t *d_tgt_off,
                         int dim, const double *d_init_T, int32_t S,

@@ -189,6 +189,16 @@ int lslam_valu_probe(int device, double* out_lane_ops_per_s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// which pruned kernel a batched call takes (0: the all-pairs sweep, which touches no workspace of the thread).
+// automatic: planar batches from kAutoPruneBatchPoints points per cloud, 3-D batches from kAutoPruneBatchPoints3D
+static int batch_prune_choice(int dim, uint32_t flags, int64_t max_src_n, int64_t max_tgt_n) {
+  const bool prune = dim == 2 ? want_pruning(flags, max_src_n >= kAutoPruneBatchPoints && max_tgt_n >= kAutoPruneBatchPoints)
+                              : want_pruning(flags, max_src_n >= kAutoPruneBatchPoints3D && max_tgt_n >= kAutoPruneBatchPoints3D);
+  if (prune && dim == 3 && icp_pruned3_supported(max_src_n, max_tgt_n)) return 3;
+  if (prune && dim == 2 && icp_pruned_supported(dim, max_src_n, max_tgt_n)) return 2;
+  return 0;
+}
+
 static int icp_batch_dev_impl(const float* d_src, const double* d_src64, const int64_t* d_src_off, const float* d_tgt,
                               const double* d_tgt64, const int64_t* d_tgt_off, int dim, const double* d_init_T, int32_t S,
                               int64_t max_src_n, int64_t max_tgt_n, double epsilon, double stopping_thresh,
@@ -207,9 +217,8 @@ static int icp_batch_dev_impl(const float* d_src, const double* d_src64, const i
   a.init_T = d_init_T; a.out_T = d_out_T; a.out_err = d_out_err; a.out_iters = d_out_iters;
   a.out_corr = d_out_corr;
   a.epsilon = epsilon; a.stopping_thresh = stopping_thresh; a.max_iters = max_iters; a.flags = flags;
-  // automatic: planar batches from kAutoPruneBatchPoints points per cloud, 3-D batches from kAutoPruneBatchPoints3D
-  const bool prune = dim == 2 ? want_pruning(flags, max_src_n >= kAutoPruneBatchPoints && max_tgt_n >= kAutoPruneBatchPoints)
-                              : want_pruning(flags, max_src_n >= kAutoPruneBatchPoints3D && max_tgt_n >= kAutoPruneBatchPoints3D);
+  const int pruned = batch_prune_choice(dim, flags, max_src_n, max_tgt_n);
+  const bool prune = pruned != 0;
   if (prune && dim == 3 && icp_pruned3_supported(max_src_n, max_tgt_n)) {
     static thread_local PruneScratch3 sc3{};
     static thread_local size_t cap3_src = 0, cap3_tgt = 0;
@@ -269,11 +278,14 @@ int lslam_icp_batch_dev64(const float* d_src, const double* d_src64, const int64
                           int32_t max_iters, uint32_t flags, double* d_out_T, double* d_out_err,
                           int32_t* d_out_iters, int32_t* d_out_corr, void* stream) {
   clear_error();
-  int rc = ws_fence().enter(static_cast<hipStream_t>(stream));
+  // only the pruned kernels use a workspace of the thread (the Morton-sorted copies): the all-pairs sweep needs no ordering
+  // against the thread's earlier calls on other streams
+  const bool uses_ws = (dim == 2 || dim == 3) && batch_prune_choice(dim, flags, max_src_n, max_tgt_n) != 0;
+  int rc = uses_ws ? ws_fence().enter(static_cast<hipStream_t>(stream)) : LSLAM_OK;
   if (rc != LSLAM_OK) return rc;
   rc = icp_batch_dev_impl(d_src, d_src64, d_src_off, d_tgt, d_tgt64, d_tgt_off, dim, d_init_T, S, max_src_n, max_tgt_n, epsilon,
                           stopping_thresh, max_iters, flags, d_out_T, d_out_err, d_out_iters, d_out_corr, stream);
-  const int rc2 = ws_fence().leave(static_cast<hipStream_t>(stream));
+  const int rc2 = uses_ws ? ws_fence().leave(static_cast<hipStream_t>(stream)) : LSLAM_OK;
   return rc != LSLAM_OK ? rc : rc2;
 }
 

@@ -53,20 +53,26 @@ pair_op_kernel(PairOpArgs a) {
 __global__ void __launch_bounds__(256) valu_probe_kernel(float* out, int iters, float seed) {
   // 64 independent v_fma_f32 per trip, written in assembly: in C++ the compiler either packs them (v_pk_fma_f32 issues
   // at half the instruction rate) or chains them through one register (measured 4 cycles per instruction instead of 2)
-  float r = seed + threadIdx.x;
-  asm volatile("v_mov_b32 v8, %0\n v_mov_b32 v20, 0\n v_mov_b32 v21, 0\n v_mov_b32 v22, 0\n v_mov_b32 v23, 0\n"
-               "v_mov_b32 v24, 0\n v_mov_b32 v25, 0\n v_mov_b32 v26, 0\n v_mov_b32 v27, 0\n"
-               :: "v"(r) : "v8", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27");
-  for (int i = 0; i < iters; ++i) {
+  // ONE asm statement holds initialisation, loop and reduction: the physical registers it names (v8, v20–v27) carry state
+  // from instruction to instruction, which separate asm statements cannot promise (clobber lists do not keep a register
+  // live between statements); the loop counter is a scalar operand the statement owns ("+s").
+  float r = seed + threadIdx.x, s;
+  int n = iters;
 #define LSLAM_FMA8 "v_fma_f32 v20, v8, 1.0, 0.5\n v_fma_f32 v21, v8, 1.0, 0.5\n v_fma_f32 v22, v8, 1.0, 0.5\n v_fma_f32 v23, v8, 1.0, 0.5\n" \
                    "v_fma_f32 v24, v8, 1.0, 0.5\n v_fma_f32 v25, v8, 1.0, 0.5\n v_fma_f32 v26, v8, 1.0, 0.5\n v_fma_f32 v27, v8, 1.0, 0.5\n"
-    asm volatile(LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8
-                 ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27");
+  asm volatile("v_mov_b32 v8, %2\n v_mov_b32 v20, 0\n v_mov_b32 v21, 0\n v_mov_b32 v22, 0\n v_mov_b32 v23, 0\n"
+               "v_mov_b32 v24, 0\n v_mov_b32 v25, 0\n v_mov_b32 v26, 0\n v_mov_b32 v27, 0\n"
+               "s_cmp_lt_i32 %1, 1\n s_cbranch_scc1 2f\n"
+               "1:\n"
+               LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8 LSLAM_FMA8
+               "s_sub_i32 %1, %1, 1\n s_cmp_gt_i32 %1, 0\n s_cbranch_scc1 1b\n"
+               "2:\n"
+               "v_add_f32 %0, v20, v21\n v_add_f32 %0, %0, v22\n v_add_f32 %0, %0, v23\n v_add_f32 %0, %0, v24\n"
+               "v_add_f32 %0, %0, v25\n v_add_f32 %0, %0, v26\n v_add_f32 %0, %0, v27\n"
+               : "=&v"(s), "+s"(n)
+               : "v"(r)
+               : "v8", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "scc");
 #undef LSLAM_FMA8
-  }
-  float s;
-  asm volatile("v_add_f32 %0, v20, v21\n v_add_f32 %0, %0, v22\n v_add_f32 %0, %0, v23\n v_add_f32 %0, %0, v24\n"
-               "v_add_f32 %0, %0, v25\n v_add_f32 %0, %0, v26\n v_add_f32 %0, %0, v27\n" : "=v"(s));
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
