@@ -83,7 +83,10 @@ def _pack_staged(clouds, dtype, slot):
     for _ in range(3):
         key = (slot, d, np.dtype(want).name)
         cap = _STAGED_POINTS.get(key, 0)
-        arr = _lib.staging_array(slot, max(cap, 1) * d, want)
+        try:
+            arr = _lib.staging_array(slot, max(cap, 1) * d, want)
+        except _lib.LslamError:                                      # no device / no pinned memory: NumPy packs
+            return None
         r = ph.pack_list(clouds, arr.ctypes.data, cap, d, int(want == np.float64), off.ctypes.data, threads)
         if r is None:
             return None

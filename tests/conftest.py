@@ -22,7 +22,8 @@ def pytest_sessionstart(session):
     import subprocess
     so = os.path.join(ROOT, "lidar_slam_amd", "lib", "liblslam_hip.so")
     hostcheck = os.path.join(ROOT, "lidar_slam_amd", "lib", "liblslam_hostcheck.so")
-    if (not os.path.exists(so) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"))) or not os.path.exists(hostcheck):
+    pyhost = os.path.join(ROOT, "lidar_slam_amd", "lib", "_lslam_pyhost.so")
+    if (not os.path.exists(so) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"))) or not os.path.exists(hostcheck) or not os.path.exists(pyhost):
         subprocess.run(["make", "-C", os.path.join(ROOT, "lidar_slam_amd", "csrc"), "-j4"], check=False,
                        stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
     if not os.path.exists(os.path.join(ROOT, "oracle", "_build", "liboracle_icp.so")):

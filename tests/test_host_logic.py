@@ -56,3 +56,47 @@ def test_pack_clouds_rejects_mixed_dimensions():
     import pytest
     with pytest.raises(ValueError):
         pack_clouds([np.zeros((3, 2)), np.zeros((3, 3))])
+
+
+def test_c_packing_helper_gathers_converts_and_checks_a_scan_list():
+    """csrc/pyhost: the list of scans walked through the buffer protocol and copied by several threads — offsets, order,
+    float32 <-> float64 conversion, the finiteness verdict, the too-small-destination answer, and its refusals"""
+    from lidar_slam_amd import _lib
+    ph = _lib.pyhost()
+    assert ph is not None, "lidar_slam_amd/lib/_lslam_pyhost.so is missing: make -C lidar_slam_amd/csrc"
+    rng = np.random.default_rng(5)
+    sizes = [0, 7, 1081, 1, 650, 0, 333] * 40
+    z = [rng.normal(size=(n, 2)) for n in sizes]
+    total = sum(sizes)
+    off = np.empty(len(z) + 1, np.int64)
+    for threads in (1, 3, 8):
+        for dst_dtype in (np.float64, np.float32):
+            dst = np.full((total, 2), -7.0, dst_dtype)
+            r = ph.pack_list(z, dst.ctypes.data, total, 2, int(dst_dtype == np.float64), off.ctypes.data, threads)
+            assert r == (total, 1, len(z))
+            np.testing.assert_array_equal(off, np.concatenate(([0], np.cumsum(sizes))))
+            np.testing.assert_array_equal(dst, np.concatenate(z).astype(dst_dtype))
+    # a float32 scan among float64 ones: converted, and counted
+    z32 = list(z); z32[3] = z32[3].astype(np.float32); z32[2] = z32[2].astype(np.float32)
+    dst = np.empty((total, 2))
+    assert ph.pack_list(z32, dst.ctypes.data, total, 2, 1, off.ctypes.data, 4) == (total, 1, len(z) - 2)
+    np.testing.assert_array_equal(dst, np.concatenate([a.astype(np.float64) for a in z32]))
+    # destination too small: nothing copied, the needed size comes back
+    assert ph.pack_list(z, dst.ctypes.data, total - 1, 2, 1, off.ctypes.data, 4)[:2] == (total, -1)
+    # a non-finite coordinate anywhere
+    bad = list(z); bad[2] = bad[2].copy(); bad[2][500, 1] = np.inf
+    assert ph.pack_list(bad, dst.ctypes.data, total, 2, 1, off.ctypes.data, 4)[1] == 0
+    # what it cannot take: wrong width, a non-contiguous view, an integer array, not a list
+    assert ph.pack_list(z + [np.zeros((3, 3))], dst.ctypes.data, total + 3, 2, 1, np.empty(len(z) + 2, np.int64).ctypes.data, 2) is None
+    assert ph.pack_list([z[2][:, ::-1]], dst.ctypes.data, total, 2, 1, off.ctypes.data, 2) is None
+    assert ph.pack_list([np.zeros((4, 2), np.int32)], dst.ctypes.data, total, 2, 1, off.ctypes.data, 2) is None
+    assert ph.pack_list(tuple(z), dst.ctypes.data, total, 2, 1, off.ctypes.data, 2) is None
+
+
+def test_pack_clouds_keeps_the_precision_it_is_given():
+    rng = np.random.default_rng(6)
+    z64 = [rng.normal(size=(n, 2)) for n in (5, 9, 2)]
+    z32 = [a.astype(np.float32) for a in z64]
+    assert pack_clouds(z64)[0].dtype == np.float64 and pack_clouds(z32)[0].dtype == np.float32
+    assert pack_clouds([z32[0], z64[1], z32[2]])[0].dtype == np.float64            # one float64 scan keeps the whole batch exact
+    assert pack_clouds(z64, dtype=np.float32)[0].dtype == np.float32

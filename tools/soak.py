@@ -1,4 +1,4 @@
-"""Randomised soak of the HIP ICP paths against the C oracle's device recipe (exact fmaf): many ragged batches of
+"""Randomised soak of the HIP ICP paths against the C oracle (float32 clouds: its device recipe, exact fmaf; float64 clouds = float64-exact mode: its float64 recipe): many ragged batches of
 random planar / 3-D problems, sizes from a handful to a few thousand points, duplicated targets, grid-aligned ties.
 Every problem must give identical iteration counts and correspondences and T within 1e-9 — on the all-pairs path,
 on the pruned path and (for the larger ones) on the whole-chip path.
@@ -66,27 +66,33 @@ t_end, rounds, problems, bad = time.time() + budget, 0, 0, 0
 while time.time() < t_end:
     dim = int(rng.choice([2, 3]))
     probs = [problem(dim) for _ in range(24)]
-    flat_s, so = pack_clouds([p[0] for p in probs])
-    flat_t, to = pack_clouds([p[1] for p in probs])
     init = np.tile(np.eye(4), (len(probs), 1, 1))
-    oracles = [c_oracle.run_icp(s, t, np.eye(4), epsilon=1e-12, max_iters=12, recipe="device") for s, t in probs]
-    # all pairs (build picked by size), exact pruning, and all pairs on the big build with the expanded-form filter at every size
-    for prune, variant in ((False, None), (True, None), (False, "1")):
-        if variant:
-            os.environ["LSLAM_ICP_VARIANT"] = variant
-        r = icp_batch(flat_s, so, flat_t, to, init, epsilon=1e-12, max_iters=12, return_correspondences=True, prune=prune)
-        os.environ.pop("LSLAM_ICP_VARIANT", None)
-        for k, o in enumerate(oracles):
-            bad += not same(f"batch prune={prune} variant={variant} dim={dim} n={probs[k][0].shape[0]} m={probs[k][1].shape[0]}", r.T[k], r.error[k],
-                            r.iterations[k], r.correspondences[so[k]:so[k + 1]], o, probs[k][1])
-    for k, (s, t) in enumerate(probs[:6]):          # the same problems on the whole-chip path (fused below 8192 points)
-        for prune in (_lib.ICP_ALL_PAIRS, _lib.ICP_PRUNE):
-            s32, t32 = np.ascontiguousarray(s, np.float32), np.ascontiguousarray(t, np.float32)
-            T = np.empty((4, 4)); e = np.empty(1); it = np.empty(1, np.int32); corr = np.empty(s.shape[0], np.int32)
-            check(lib().lslam_icp_large(ptr(s32), s.shape[0], ptr(t32), t.shape[0], dim, ptr(np.eye(4)), 1e-12, 1e-4, 12, prune,
-                                        ptr(T), ptr(e), ptr(it), ptr(corr), 0))
-            bad += not same(f"whole-chip prune={prune == _lib.ICP_PRUNE} dim={dim} n={s.shape[0]} m={t.shape[0]}", T, e[0], it[0], corr, oracles[k], t)
+    # both precision modes: float32 clouds against the oracle's device recipe, float64 clouds (float64-exact mode) against its float64 recipe
+    for mode, dtype, recipe in (("f32", np.float32, "device"), ("f64", np.float64, "f64")):
+        flat_s, so = pack_clouds([p[0] for p in probs], dtype=dtype)
+        flat_t, to = pack_clouds([p[1] for p in probs], dtype=dtype)
+        oracles = [c_oracle.run_icp(s, t, np.eye(4), epsilon=1e-12, max_iters=12, recipe=recipe) for s, t in probs]
+        # all pairs (build picked by size), exact pruning, and all pairs on the big build with the expanded-form filter at every size
+        for prune, variant in ((False, None), (True, None), (False, "1")):
+            if variant:
+                os.environ["LSLAM_ICP_VARIANT"] = variant
+            r = icp_batch(flat_s, so, flat_t, to, init, epsilon=1e-12, max_iters=12, return_correspondences=True, prune=prune)
+            os.environ.pop("LSLAM_ICP_VARIANT", None)
+            for k, o in enumerate(oracles):
+                bad += not same(f"{mode} batch prune={prune} variant={variant} dim={dim} n={probs[k][0].shape[0]} m={probs[k][1].shape[0]}", r.T[k], r.error[k],
+                                r.iterations[k], r.correspondences[so[k]:so[k + 1]], o, probs[k][1])
+        # the same problems on the whole-chip paths: the co-resident one-launch kernel where it applies, else launches per iteration
+        entry = lib().lslam_icp_large_f64 if mode == "f64" else lib().lslam_icp_large
+        for k, (s, t) in enumerate(probs[:6]):
+            for prune, coop in ((_lib.ICP_ALL_PAIRS, "1"), (_lib.ICP_ALL_PAIRS, "0"), (_lib.ICP_PRUNE, "1")):
+                os.environ["LSLAM_ICP_COOP"] = coop
+                sc, tc = np.ascontiguousarray(s, dtype), np.ascontiguousarray(t, dtype)
+                T = np.empty((4, 4)); e = np.empty(1); it = np.empty(1, np.int32); corr = np.empty(s.shape[0], np.int32)
+                check(entry(ptr(sc), s.shape[0], ptr(tc), t.shape[0], dim, ptr(np.eye(4)), 1e-12, 1e-4, 12, prune,
+                            ptr(T), ptr(e), ptr(it), ptr(corr), 0))
+                bad += not same(f"{mode} whole-chip prune={prune == _lib.ICP_PRUNE} coop={coop} dim={dim} n={s.shape[0]} m={t.shape[0]}", T, e[0], it[0], corr, oracles[k], t)
+        os.environ.pop("LSLAM_ICP_COOP", None)
     rounds += 1; problems += len(probs)
     print(f"round {rounds}: {problems} problems so far, {bad} mismatches", flush=True)   # a silent long run is taken to be hung
-print(f"soak: {rounds} rounds, {problems} problems x (all-pairs, pruned, filter build) + {6 * rounds} x whole-chip (both): {bad} mismatches ({undefined} comparisons on rank-one matches skipped: parity undefined)")
+print(f"soak: {rounds} rounds, {problems} problems x 2 precision modes x (all-pairs, pruned, filter build) + {6 * rounds} x 2 modes x whole-chip (co-resident, per-iteration launches, pruned): {bad} mismatches ({undefined} comparisons on rank-one matches skipped: parity undefined)")
 sys.exit(1 if bad else 0)
