@@ -900,3 +900,51 @@ def test_full_size_c4_batch_vs_oracle(icp, prec):
     a = icp_batch(src, w.src_off, tgt, w.tgt_off, w.init_T, epsilon=1e-3, prune=False)
     np.testing.assert_array_equal(a.iterations, r.iterations)
     np.testing.assert_allclose(a.T, r.T, atol=1e-10)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_filter_bound_with_sources_far_from_a_target_at_the_origin(icp, dim, monkeypatch, prec):
+    """advisor, round 2: the d² coefficient of the filter's window (9u planar, 11u in 3-D) matters when d² ≫ R(R + |a|) is
+    NOT dominated by the E term — a target cloud near the origin (R ≈ 1) and sources 10–40 R away.  Batched filter build and
+    whole-chip filter search against the C oracle and against the same builds with the filter off; identity start so that the
+    first iterations really search from far away."""
+    from lidar_slam_amd.batch import icp_batch
+    from lidar_slam_amd._lib import check, lib, ptr
+    from oracle import c_oracle
+    rng = np.random.default_rng(900 + dim)
+    monkeypatch.setenv("LSLAM_ICP_VARIANT", "1")
+    cases = []
+    for n, m, shift in ((3000, 4000, 12.0), (2500, 2048, 40.0), (700, 333, 25.0)):
+        t = rng.normal(size=(m, dim)) * 0.4                       # R ≈ 1.5
+        s = rng.normal(size=(n, dim)) * 0.4
+        s[:, 0] += shift                                          # ≥ 10 R away
+        t[m // 3] = t[7]                                          # an exact duplicate
+        cases.append((s, t))
+    fs, so = prec.pack([c[0] for c in cases]); ft, to = prec.pack([c[1] for c in cases])
+    I = np.tile(np.eye(4), (len(cases), 1, 1))
+    kw = dict(epsilon=1e-12, max_iters=3, return_correspondences=True, prune=False)
+    a = icp_batch(fs, so, ft, to, I, **kw)
+    for k, (s_, t_) in enumerate(cases):
+        To, eo, co, ito = c_oracle.run_icp(s_, t_, np.eye(4), epsilon=1e-12, max_iters=3, recipe=prec.recipe)
+        assert a.iterations[k] == ito
+        np.testing.assert_array_equal(a.correspondences[so[k]:so[k + 1]], co)
+        np.testing.assert_allclose(a.T[k], To, atol=1e-9)
+    monkeypatch.setenv("LSLAM_ICP_FILTER", "0")
+    b = icp_batch(fs, so, ft, to, I, **kw)
+    np.testing.assert_array_equal(a.correspondences, b.correspondences)
+    np.testing.assert_array_equal(a.T, b.T)
+    monkeypatch.delenv("LSLAM_ICP_FILTER")
+    # whole-chip filter search (two / four source points per lane), three launches per iteration
+    monkeypatch.setenv("LSLAM_ICP_FUSE_TAIL", "0")
+    n, m = (9000 if dim == 3 else 66000), 6007
+    t = rng.normal(size=(m, dim)) * 0.4
+    s = rng.normal(size=(n, dim)) * 0.4
+    s[:, 1] -= 30.0
+    entry = lib().lslam_icp_large_f64 if prec.name == "f64" else lib().lslam_icp_large
+    To, eo, co, ito = c_oracle.run_icp(s, t, np.eye(4), epsilon=1e-12, max_iters=2, recipe=prec.recipe)
+    sc, tc = prec.cast(s), prec.cast(t)
+    T = np.empty((4, 4)); err = np.empty(1); it = np.empty(1, np.int32); corr = np.empty(n, np.int32)
+    check(entry(ptr(sc), n, ptr(tc), m, dim, ptr(np.eye(4)), 1e-12, 1e-4, 2, 4, ptr(T), ptr(err), ptr(it), ptr(corr), 0))
+    assert it[0] == ito
+    np.testing.assert_array_equal(corr, co)
+    np.testing.assert_allclose(T, To, atol=1e-9)
