@@ -172,7 +172,8 @@ int lslam_icp_large_dev(const float *d_src, int64_t n, const float *d_tgt, int64
                         int32_t *d_out_corr, void *stream);
 
 /* float64-exact mode of the two entry points above (see lslam_icp_batch_f64): the float64 clouds decide near
- * ties and feed the moments.  Pruning is not available in this mode (the flag is ignored: all pairs). */
+ * ties and feed the moments.  Both search strategies are available (the pruned search adds one refine launch per
+ * iteration for the sources with a near tie). */
 int lslam_icp_large_f64(const double *src, int64_t n, const double *tgt, int64_t m, int dim,
                         const double *init_T, double epsilon, double stopping_thresh,
                         int32_t max_iters, uint32_t flags,

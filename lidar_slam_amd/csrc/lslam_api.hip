@@ -538,7 +538,7 @@ struct LpHolder {
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     ws->temp_bytes = lp_sort_temp_bytes(mx);
     const size_t need = al(pt * n) + al(4 * n) + al(pt * m) + al(4 * m) + 2 * (al(16 * n1) + al(16 * n2) + al(16 * n3)) + al(4 * n) +
-                        4 * al(4 * mx) + al(4 * 6 * 1024) + al(64) + al(ws->temp_bytes);
+                        4 * al(4 * mx) + al(4 * 6 * 1024) + al(64) + al(ws->temp_bytes) + al(64) + 2 * al(4 * n);
     if (dev != device || need > cap) {
       if (block) { (void)hipDeviceSynchronize(); (void)hipFree(block); }
       block = nullptr; cap = 0; device = dev;
@@ -558,6 +558,9 @@ struct LpHolder {
     ws->bbox_partial = static_cast<float*>(take(4 * 6 * 1024));
     ws->grid = static_cast<float*>(take(64));
     ws->temp = take(ws->temp_bytes);
+    ws->flag_count = static_cast<int32_t*>(take(64));
+    ws->flag_src = static_cast<int32_t*>(take(4 * n));
+    ws->flag_lim = static_cast<float*>(take(4 * n));
     return LSLAM_OK;
   }
 };
@@ -580,8 +583,7 @@ static int icp_large_dev_impl(const float* d_src, const double* d_src64, int64_t
   int dev = 0;
   LSLAM_HIP_TRY(hipGetDevice(&dev));
   LargeWs& ws = large_ws();
-  // float64-exact mode: the pruned whole-chip search has no float64 refinement — all pairs there
-  const bool prune = !f64 && want_pruning(flags, (double)n * (double)m >= (dim == 2 ? kAutoPruneLargePairEvals2D : kAutoPruneLargePairEvals3D));
+  const bool prune = want_pruning(flags, (double)n * (double)m >= (dim == 2 ? kAutoPruneLargePairEvals2D : kAutoPruneLargePairEvals3D));
   const NnGeometry geo = nn_geometry(dim, n, m);
   int rc = ws.ensure(dev, prune ? 1 : n * geo.splits);
   if (rc != LSLAM_OK) return rc;
@@ -619,8 +621,8 @@ static int icp_large_dev_impl(const float* d_src, const double* d_src64, int64_t
     *out_iters = ws.h_back[0]->stop.executed;
     return LSLAM_OK;
   }
-  if (f64) {                                                // three launches per iteration, the moments kernel decides the near ties
-    if ((rc = ws.ensure_sec(n * geo.splits)) != LSLAM_OK) return rc;
+  if (f64) {                                                // the near ties are decided by the moments kernel (all pairs) / a refine launch (pruned)
+    if ((rc = ws.ensure_sec(prune ? 1 : n * geo.splits)) != LSLAM_OK) return rc;
     LSLAM_HIP_TRY(launch_cloud_bounds(d_src, n, d_tgt, m, dim, ws.bounds, st));
   }
   LpWs lp{};
@@ -673,7 +675,18 @@ static int icp_large_dev_impl(const float* d_src, const double* d_src64, int64_t
         LpMomArgs pm{};
         pm.src_sorted = lp.src_sorted; pm.src_index = lp.src_index; pm.n = n; pm.tgt_sorted = lp.tgt_sorted; pm.tgt_index = lp.tgt_index;
         pm.match = lp.match; pm.state = ws.state; pm.partials = ws.partials; pm.out_corr = d_out_corr; pm.flags = flags;
+        if (f64) {
+          pa.bounds = ws.bounds; pa.flag_count = lp.flag_count; pa.flag_src = lp.flag_src; pa.flag_lim = lp.flag_lim;
+          pm.src64 = d_src64; pm.tgt64 = d_tgt64;
+        }
         LSLAM_HIP_TRY(lp_launch_nn(dim, pa, st));
+        if (f64) {
+          LpRefineArgs ra{};
+          ra.src_sorted = lp.src_sorted; ra.src_index = lp.src_index; ra.tgt_sorted = lp.tgt_sorted; ra.tgt_index = lp.tgt_index; ra.m = m;
+          ra.src64 = d_src64; ra.tgt64 = d_tgt64; ra.state = ws.state;
+          ra.flag_count = lp.flag_count; ra.flag_src = lp.flag_src; ra.flag_lim = lp.flag_lim; ra.match = lp.match;
+          LSLAM_HIP_TRY(lp_launch_refine(dim, ra, st));
+        }
         LSLAM_HIP_TRY(lp_launch_moments(dim, pm, rows, st));
       } else {
         LSLAM_HIP_TRY(launch_nn(na, dim, geo, st));

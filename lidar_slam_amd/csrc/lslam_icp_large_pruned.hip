@@ -160,7 +160,10 @@ __device__ __forceinline__ float lane_value(float v, int k) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(k)));
 }
 
-template <int DIM, int P>
+// F64: float64-exact mode (lslam_device.h: NearTie) — every box test compares against reach(best) = the near-tie window, the second
+// smallest distance of the evaluated targets is tracked, and a source whose second is within lim(best) goes on a list that
+// lp_refine_kernel decides on the float64 points
+template <int DIM, int P, bool F64>
 __global__ void __launch_bounds__(kLpThreads)
 nn_pruned_kernel(LpNnArgs a) {
   constexpr int CH = NnChunk<DIM>::value;
@@ -178,7 +181,18 @@ nn_pruned_kernel(LpNnArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) T[r][c] = wave_uniform(a.state->T[4 * r + c]);
 
+  NearTie nt = near_tie_setup(false, 0.f, 0.f, 0.f);
+  if constexpr (F64) {
+    double f2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < DIM; ++r)
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) f2 += T[r][c] * T[r][c];
+    nt = near_tie_setup(true, sqrtf(a.bounds[0]) * 1.0001f, sqrtf(a.bounds[1]) * 1.0001f, sqrtf((float)f2) * 1.0001f);
+  }
+  auto reach = [&](float b) { return F64 ? __builtin_fmaf(b, nt.K1, nt.C) : b; };
   float s[P][DIM];
+  float second[P];                                          // F64: second smallest distance among the targets evaluated (not the winner itself)
   float wlo[3] = {INFINITY, INFINITY, INFINITY}, whi[3] = {-INFINITY, -INFINITY, -INFINITY};
   // per source: the best candidate so far as the lexicographic minimum of (distance, ORIGINAL index) —
   // kept exactly at every evaluation, so ties need no second pass
@@ -190,6 +204,7 @@ nn_pruned_kernel(LpNnArgs a) {
   for (int p = 0; p < P; ++p) {
     const int64_t i = ((int64_t)blockIdx.x * kLpThreads + threadIdx.x) * P + p;
     best[p] = -INFINITY;                                    // lanes without a point never ask for a box
+    second[p] = INFINITY;
     bidx[p] = 0x7fffffff;
     bpos[p] = 0;
 #pragma unroll
@@ -236,9 +251,9 @@ nn_pruned_kernel(LpNnArgs a) {
   // The 64 lanes test 64 sibling boxes at once (one coalesced load); a box matters iff its bound does
   // not exceed the largest current best of the wave.
   auto wave_best = [&]() -> float {
-    float w = best[0];
+    float w = reach(best[0]);
 #pragma unroll
-    for (int p = 1; p < P; ++p) w = fmaxf(w, best[p]);
+    for (int p = 1; p < P; ++p) w = fmaxf(w, reach(best[p]));
     return lp_wave_max(w);
   };
   // stage 1 — the 64 lanes test 64 sibling boxes at once against the WAVE's box (one coalesced load)
@@ -269,7 +284,7 @@ nn_pruned_kernel(LpNnArgs a) {
         const float dz = fmaxf(fmaxf(lz - s[p][2], s[p][2] - hz), 0.f);
         lb = __builtin_fmaf(dz, dz, lb);
       }
-      need |= best[p] >= lb * kLpSafety;
+      need |= reach(best[p]) >= lb * kLpSafety;
     }
     return __any(need) != 0;
   };
@@ -323,6 +338,10 @@ nn_pruned_kernel(LpNnArgs a) {
       for (int p = 0; p < P; ++p) {
         const float d = lp_dist<DIM>(s[p], qx, qy, qz);
         const bool better = (d < best[p]) || (d == best[p] && o < bidx[p]);
+        if constexpr (F64) {                                // the winner's own re-evaluation (the seed is met again in its chunk) does not count
+          const float s2 = __builtin_amdgcn_fmed3f(best[p], second[p], d);
+          second[p] = (o == bidx[p]) ? second[p] : s2;
+        }
         improved |= better;
         best[p] = better ? d : best[p];
         bidx[p] = better ? o : bidx[p];
@@ -371,7 +390,79 @@ nn_pruned_kernel(LpNnArgs a) {
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int64_t i = ((int64_t)blockIdx.x * kLpThreads + threadIdx.x) * P + p;
-    if (i < a.n) a.match[i] = (int32_t)bpos[p];
+    if (i < a.n) {
+      a.match[i] = (int32_t)bpos[p];
+      if constexpr (F64) {
+        const float lim = near_lim(best[p], nt);
+        if (second[p] <= lim) {                             // a near tie: decided on the float64 points by lp_refine_kernel
+          const int e = atomicAdd(a.flag_count, 1);
+          a.flag_src[e] = (int32_t)i;
+          a.flag_lim[e] = lim;
+        }
+      }
+    }
+  }
+}
+
+// float64-exact mode: one workgroup per flagged source scans the whole sorted target; every target whose float32 distance is
+// within the window is evaluated in float64 on the float64 points; the nearest wins, lowest ORIGINAL index on float64 ties
+template <int DIM>
+__global__ void __launch_bounds__(kLpThreads)
+lp_refine_kernel(LpRefineArgs a) {
+  using SP = typename SortedPoint<DIM>::type;
+  __shared__ unsigned long long s_best, s_key;
+  if (a.state->done) return;
+  const SP* __restrict__ src = reinterpret_cast<const SP*>(a.src_sorted);
+  const SP* __restrict__ tgt = reinterpret_cast<const SP*>(a.tgt_sorted);
+  const int count = *a.flag_count;
+  double T[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) T[r][c] = a.state->T[4 * r + c];
+  for (int e = blockIdx.x; e < count; e += gridDim.x) {
+    const int i = a.flag_src[e];
+    const float lim = a.flag_lim[e];
+    const SP v = src[i];
+    const int so = a.src_index[i];
+    float af[DIM];
+    double ad[DIM];
+    {
+      const double x = v.x, y = v.y;
+      double z = 0.0;
+      if constexpr (DIM == 3) z = v.z;
+      const double xd = a.src64[(int64_t)DIM * so], yd = a.src64[(int64_t)DIM * so + 1];
+      double zd = 0.0;
+      if constexpr (DIM == 3) zd = a.src64[(int64_t)DIM * so + 2];
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) {
+        double t = T[r][0] * x + T[r][1] * y + T[r][3], td = T[r][0] * xd + T[r][1] * yd + T[r][3];
+        if constexpr (DIM == 3) { t += T[r][2] * z; td += T[r][2] * zd; }
+        af[r] = (float)t;                                   // what the search saw
+        ad[r] = td;                                         // icp.py:116 on the float64 point
+      }
+    }
+    if (threadIdx.x == 0) { s_best = ~0ull; s_key = ~0ull; }
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int64_t j = threadIdx.x; j < a.m; j += kLpThreads) {
+        const SP q = tgt[j];
+        float qz = 0.f;
+        if constexpr (DIM == 3) qz = q.z;
+        if (lp_dist<DIM>(af, q.x, q.y, qz) <= lim) {
+          const int o = a.tgt_index[j];
+          double ev = 0.0;
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) { const double df = ad[r] - a.tgt64[(int64_t)DIM * o + r]; ev += df * df; }
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(ev);      // non-negative doubles order like their bits
+          if (pass == 0) atomicMin(&s_best, bits);
+          else if (bits == s_best) atomicMin(&s_key, ((unsigned long long)(unsigned)o << 32) | (unsigned long long)(unsigned)j);
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0 && s_key != ~0ull) a.match[i] = (int32_t)(unsigned)(s_key & 0xffffffffull);
+    __syncthreads();
   }
 }
 
@@ -395,20 +486,27 @@ moments_sorted_kernel(LpMomArgs a) {
   for (int64_t i = (int64_t)blockIdx.x * kMomThreads + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kMomThreads) {
     const int32_t j = a.match[i];
     if (a.out_corr) a.out_corr[a.src_index[i]] = a.tgt_index[j];
-    const SP v = src[i];
-    const SP w = tgt[j];
-    const double x = v.x, y = v.y;
-    double z = 0.0;
-    if constexpr (DIM == 3) z = v.z;
-    double p[DIM], q[DIM];
+    double x, y, z = 0.0, p[DIM], q[DIM];
+    if (a.src64) {                                          // float64-exact mode: the float64 points themselves (original order)
+      const int64_t so = a.src_index[i], to = a.tgt_index[j];
+      x = a.src64[DIM * so]; y = a.src64[DIM * so + 1];
+      if constexpr (DIM == 3) z = a.src64[DIM * so + 2];
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) q[r] = a.tgt64[DIM * to + r];
+    } else {
+      const SP v = src[i];
+      const SP w = tgt[j];
+      x = v.x; y = v.y;
+      if constexpr (DIM == 3) z = v.z;
+      q[0] = w.x; q[1] = w.y;
+      if constexpr (DIM == 3) q[2] = w.z;
+    }
 #pragma unroll
     for (int r = 0; r < DIM; ++r) {
       double t = T[r][0] * x + T[r][1] * y + T[r][3];
       if constexpr (DIM == 3) t += T[r][2] * z;
       p[r] = t;
     }
-    q[0] = w.x; q[1] = w.y;
-    if constexpr (DIM == 3) q[2] = w.z;
     acc.add(p, q, box);
   }
   acc.wave_reduce(box);
@@ -483,8 +581,21 @@ hipError_t lp_prepare(int dim, const float* d_src, int64_t n, const float* d_tgt
 hipError_t lp_launch_nn(int dim, const LpNnArgs& a, hipStream_t st) {
   constexpr int P = 1;                 // as many independent waves as possible: the search is latency-bound
   const unsigned blocks = (unsigned)((a.n + (int64_t)kLpThreads * P - 1) / ((int64_t)kLpThreads * P));
-  if (dim == 2) hipLaunchKernelGGL((nn_pruned_kernel<2, P>), dim3(blocks), dim3(kLpThreads), 0, st, a);
-  else hipLaunchKernelGGL((nn_pruned_kernel<3, P>), dim3(blocks), dim3(kLpThreads), 0, st, a);
+  if (a.flag_count) {                                       // float64-exact mode
+    hipError_t e = hipMemsetAsync(a.flag_count, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return e;
+    if (dim == 2) hipLaunchKernelGGL((nn_pruned_kernel<2, P, true>), dim3(blocks), dim3(kLpThreads), 0, st, a);
+    else hipLaunchKernelGGL((nn_pruned_kernel<3, P, true>), dim3(blocks), dim3(kLpThreads), 0, st, a);
+    return hipGetLastError();
+  }
+  if (dim == 2) hipLaunchKernelGGL((nn_pruned_kernel<2, P, false>), dim3(blocks), dim3(kLpThreads), 0, st, a);
+  else hipLaunchKernelGGL((nn_pruned_kernel<3, P, false>), dim3(blocks), dim3(kLpThreads), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t lp_launch_refine(int dim, const LpRefineArgs& a, hipStream_t st) {
+  if (dim == 2) hipLaunchKernelGGL(lp_refine_kernel<2>, dim3(512), dim3(kLpThreads), 0, st, a);
+  else hipLaunchKernelGGL(lp_refine_kernel<3>, dim3(512), dim3(kLpThreads), 0, st, a);
   return hipGetLastError();
 }
 

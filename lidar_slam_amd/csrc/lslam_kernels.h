@@ -209,6 +209,7 @@ struct LpWs {                      // device workspace of one problem
   unsigned *keys_in, *keys_out, *vals_in, *vals_out;
   float* bbox_partial;                         // 1024 x 6
   float* grid;                                 // lo[3], scale[3]
+  int32_t* flag_count; int32_t* flag_src; float* flag_lim;     // float64-exact mode: near-tie list (n entries)
   void* temp; size_t temp_bytes;
 };
 struct LpTree { int64_t n1, n2, n3; };
@@ -219,6 +220,18 @@ struct LpNnArgs {
   int64_t n1, n2, n3;
   int32_t* match;
   const LargeState* state;
+  // float64-exact mode: {max |t|², max |p|²} of the clouds, and the list of sources with a near tie (sorted source index,
+  // window) that lp_launch_refine then decides on the float64 points
+  const float* bounds;
+  int32_t* flag_count; int32_t* flag_src; float* flag_lim;
+};
+struct LpRefineArgs {
+  const void* src_sorted; const int32_t* src_index;
+  const void* tgt_sorted; const int32_t* tgt_index; int64_t m;
+  const double* src64; const double* tgt64;
+  const LargeState* state;
+  const int32_t* flag_count; const int32_t* flag_src; const float* flag_lim;
+  int32_t* match;
 };
 struct LpMomArgs {
   const void* src_sorted; const int32_t* src_index; int64_t n;
@@ -228,11 +241,13 @@ struct LpMomArgs {
   double* partials;
   int32_t* out_corr;
   uint32_t flags;
+  const double* src64; const double* tgt64;    // float64-exact mode (original order), else nullptr
 };
 size_t lp_sort_temp_bytes(int64_t n);
 hipError_t lp_prepare(int dim, const float* d_src, int64_t n, const float* d_tgt, int64_t m, const double* init_T,
                       const LpWs& ws, LpTree* tree, hipStream_t st);
 hipError_t lp_launch_nn(int dim, const LpNnArgs& a, hipStream_t st);
+hipError_t lp_launch_refine(int dim, const LpRefineArgs& a, hipStream_t st);
 hipError_t lp_launch_moments(int dim, const LpMomArgs& a, int rows, hipStream_t st);
 
 // ---- float64 pair operators (lslam_ops.hip) -------------------------------------------------------
