@@ -685,6 +685,7 @@ static int icp_large_dev_impl(const float* d_src, const double* d_src64, int64_t
           ra.src_sorted = lp.src_sorted; ra.src_index = lp.src_index; ra.tgt_sorted = lp.tgt_sorted; ra.tgt_index = lp.tgt_index; ra.m = m;
           ra.src64 = d_src64; ra.tgt64 = d_tgt64; ra.state = ws.state;
           ra.flag_count = lp.flag_count; ra.flag_src = lp.flag_src; ra.flag_lim = lp.flag_lim; ra.match = lp.match;
+          ra.lo1 = lp.lo1; ra.hi1 = lp.hi1; ra.n1 = tree.n1;
           LSLAM_HIP_TRY(lp_launch_refine(dim, ra, st));
         }
         LSLAM_HIP_TRY(lp_launch_moments(dim, pm, rows, st));

@@ -445,18 +445,28 @@ lp_refine_kernel(LpRefineArgs a) {
     if (threadIdx.x == 0) { s_best = ~0ull; s_key = ~0ull; }
     __syncthreads();
     for (int pass = 0; pass < 2; ++pass) {
-      for (int64_t j = threadIdx.x; j < a.m; j += kLpThreads) {
-        const SP q = tgt[j];
-        float qz = 0.f;
-        if constexpr (DIM == 3) qz = q.z;
-        if (lp_dist<DIM>(af, q.x, q.y, qz) <= lim) {
-          const int o = a.tgt_index[j];
-          double ev = 0.0;
+      // a thread looks at whole chunks: the chunk's box first (a candidate lies within √lim of the point), its CH targets only then
+      for (int64_t c = threadIdx.x; c < a.n1; c += kLpThreads) {
+        const float4 lo = a.lo1[c], hi = a.hi1[c];
+        const float dx = fmaxf(fmaxf(lo.x - af[0], af[0] - hi.x), 0.f), dy = fmaxf(fmaxf(lo.y - af[1], af[1] - hi.y), 0.f);
+        float lb = __builtin_fmaf(dy, dy, dx * dx);
+        if constexpr (DIM == 3) { const float dz = fmaxf(fmaxf(lo.z - af[2], af[2] - hi.z), 0.f); lb = __builtin_fmaf(dz, dz, lb); }
+        if (lb * kLpSafety > lim) continue;
+        for (int k = 0; k < NnChunk<DIM>::value; ++k) {
+          const int64_t j = c * NnChunk<DIM>::value + k;
+          if (j >= a.m) break;
+          const SP q = tgt[j];
+          float qz = 0.f;
+          if constexpr (DIM == 3) qz = q.z;
+          if (lp_dist<DIM>(af, q.x, q.y, qz) <= lim) {
+            const int o = a.tgt_index[j];
+            double ev = 0.0;
 #pragma unroll
-          for (int r = 0; r < DIM; ++r) { const double df = ad[r] - a.tgt64[(int64_t)DIM * o + r]; ev += df * df; }
-          const unsigned long long bits = (unsigned long long)__double_as_longlong(ev);      // non-negative doubles order like their bits
-          if (pass == 0) atomicMin(&s_best, bits);
-          else if (bits == s_best) atomicMin(&s_key, ((unsigned long long)(unsigned)o << 32) | (unsigned long long)(unsigned)j);
+            for (int r = 0; r < DIM; ++r) { const double df = ad[r] - a.tgt64[(int64_t)DIM * o + r]; ev += df * df; }
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(ev);      // non-negative doubles order like their bits
+            if (pass == 0) atomicMin(&s_best, bits);
+            else if (bits == s_best) atomicMin(&s_key, ((unsigned long long)(unsigned)o << 32) | (unsigned long long)(unsigned)j);
+          }
         }
       }
       __syncthreads();

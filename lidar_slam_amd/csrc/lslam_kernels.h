@@ -232,6 +232,7 @@ struct LpRefineArgs {
   const LargeState* state;
   const int32_t* flag_count; const int32_t* flag_src; const float* flag_lim;
   int32_t* match;
+  const float4 *lo1, *hi1; int64_t n1;       // boxes of the target's chunks (level 1 of the hierarchy)
 };
 struct LpMomArgs {
   const void* src_sorted; const int32_t* src_index; int64_t n;
