@@ -490,10 +490,14 @@ def other_config(name, a, torch, device, stream, timed):
         from oracle.ogm_oracle import OccupancyGridOracle
         seq, _ = _sequence()
         OccupancyGridMap(0.05, 30, 30, -30, -30).build_map(seq.true_poses[:64], seq.z_ts[:64])      # warm-up
-        g = OccupancyGridMap(0.05, 30, 30, -30, -30)                                               # main.py --res 0.05 --width 60 --height 60
+        def build():
+            g_ = OccupancyGridMap(0.05, 30, 30, -30, -30)                                          # main.py --res 0.05 --width 60 --height 60
+            g_.build_map(seq.true_poses, seq.z_ts)
+            return g_
         t0 = time.perf_counter()
-        g.build_map(seq.true_poses, seq.z_ts)
-        dt = time.perf_counter() - t0
+        g = build()                                      # first call at this size (grows the staging buffer and the ray records)
+        first_s = time.perf_counter() - t0
+        dt = min(_wall(build) for _ in range(3))
         rays = int(sum(z.shape[0] for z in seq.z_ts))
         k = 16                                          # bounded CPU sample: the oracle's per-ray loop (ogm.py:172-185 restated)
         o = OccupancyGridOracle(0.05, 30, 30, -30, -30)
@@ -507,7 +511,7 @@ def other_config(name, a, torch, device, stream, timed):
         g2 = OccupancyGridMap(0.05, 30, 30, -30, -30)
         g2.build_map(seq.true_poses[:k], seq.z_ts[:k])
         return {"workload": "OGM build_map: 4956 scans of the C3 sequence into a 1201x1201 grid (res 0.05), host arrays in (PCIe included)",
-                "seconds": dt, "scans_per_sec": len(seq.z_ts) / dt, "rays_per_sec": rays / dt,
+                "seconds": dt, "seconds_first_call": first_s, "scans_per_sec": len(seq.z_ts) / dt, "rays_per_sec": rays / dt,
                 "cell_updates_per_sec": cells / k * len(seq.z_ts) / dt, "cell_updates_per_scan": cells / k,
                 "roofline_note": "no scattered HBM access: ray records -> per-(scan, 64x64 tile) LDS accumulation -> coalesced int16 count planes -> per-cell apply in scan order; tile kernel bound by the LDS walk, apply kernel by its float64 update chain; see DESIGN.md 3.4 and profiles/r01/bench_default_kernel_stats.csv",
                 "cpu_port_seconds_per_scan": cpu_s, "cpu_port_extrapolated_seconds": cpu_s * len(seq.z_ts),
@@ -622,15 +626,20 @@ def other_config(name, a, torch, device, stream, timed):
         seq, gen_s = _sequence()
         scan_matching_relative_poses(seq.x_ts[:64], seq.z_ts[:64])                     # warm-up
         _warm_gpu()
+        def stage():
+            rel_, info_ = scan_matching_relative_poses(seq.x_ts, seq.z_ts, return_info=True)   # float64 scans: float64-exact mode
+            return rel_, info_, chain_poses(rel_)
         t0 = time.perf_counter()
-        rel, info = scan_matching_relative_poses(seq.x_ts, seq.z_ts, return_info=True)       # float64 scans: float64-exact mode
-        poses = chain_poses(rel)
-        stage_s = time.perf_counter() - t0
+        rel, info, poses = stage()                      # first call at this size: grows the pinned staging buffer and the device arena
+        first_s = time.perf_counter() - t0
+        stage_s = min(_wall(stage) for _ in range(3))    # every later call of a pipeline that processes sequence after sequence
         z32 = [z.astype(np.float32) for z in seq.z_ts]
-        scan_matching_relative_poses(seq.x_ts[:64], z32[:64])
-        t0 = time.perf_counter()
-        rel32, info32 = scan_matching_relative_poses(seq.x_ts, z32, return_info=True)        # float32 scans: float32 search only
-        stage32_s = time.perf_counter() - t0
+        scan_matching_relative_poses(seq.x_ts, z32)
+        res32 = {}
+        def stage32():
+            res32["r"] = scan_matching_relative_poses(seq.x_ts, z32, return_info=True)        # float32 scans: float32 search only
+        stage32_s = min(_wall(stage32) for _ in range(3))
+        rel32, info32 = res32["r"]
         # CPU baseline on a bounded sample of the same sequence (oracle KDTree port = reference algorithm)
         from oracle import se2_oracle
         n = 400
@@ -639,7 +648,7 @@ def other_config(name, a, torch, device, stream, timed):
         cpu_s = time.perf_counter() - t0
         same = int(np.sum(info.iterations[:n] == it_cpu))
         out = {"workload": "C3 dataset-20-like sequence: 4955 consecutive scan pairs (650-1081 pts), natural convergence, host arrays in/out (PCIe + chain included)",
-               "stage_seconds": stage_s, "stage_seconds_float32_scans": stage32_s, "iteration_counts_differ_float32_vs_float64_exact": int(np.sum(info.iterations != info32.iterations)),
+               "stage_seconds": stage_s, "stage_seconds_first_call": first_s, "stage_seconds_float32_scans": stage32_s, "iteration_counts_differ_float32_vs_float64_exact": int(np.sum(info.iterations != info32.iterations)),
                "max_rel_pose_difference_float32_vs_float64_exact": float(np.abs(rel - rel32).max()),
                "scan_pairs_per_sec": 4955 / stage_s, "total_iterations": int(info.iterations.sum()),
                "cpu_port_seconds_per_pair": cpu_s / n, "cpu_port_extrapolated_seconds": cpu_s / n * 4955,
@@ -657,6 +666,12 @@ def _warm_gpu(seconds=0.25):
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         lib().lslam_valu_probe(0, ctypes.byref(v))
+
+
+def _wall(fn):
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
 
 
 def _time(torch, fn, warm, reps):

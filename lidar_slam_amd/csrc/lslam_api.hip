@@ -385,7 +385,9 @@ static int icp_batch_host(const PT* src, const int64_t* src_off, const PT* tgt, 
   // their way over PCIe (a second stream + one event per chunk).  Problems are independent (modules/localization.py:116-123),
   // so the results do not depend on the split.  (Offsets grow with the problem index: check_offsets above.)
   constexpr int kChunks = 4;
-  const bool pipelined = S >= 4 * kChunks && (b_src + b_tgt + b_src64 + b_tgt64) >= (size_t)(8u << 20) && !getenv("LSLAM_NO_UPLOAD_PIPELINE");
+  // only batches that fill the chip several times over: every chunk is a launch of its own, and a launch of fewer problems
+  // than the chip has room for (256 CUs x 1-3 workgroups) runs as long as its slowest problem (C1: 96 problems, 2.4x slower in 4 chunks)
+  const bool pipelined = S >= 512 * kChunks && (b_src + b_tgt + b_src64 + b_tgt64) >= (size_t)(8u << 20) && !getenv("LSLAM_NO_UPLOAD_PIPELINE");
   if (!pipelined) {
     if ((rc = upload(src, d_src, d_src64, 0, up_src, st)) != LSLAM_OK) return rc;
     if (!shared && (rc = upload(tgt, d_tgt, d_tgt64, 0, tot_m, st)) != LSLAM_OK) return rc;
