@@ -14,7 +14,8 @@ line = open(os.path.join(I, "bench_default_n1.json")).read().strip().splitlines(
 bench = json.loads(line)
 open(os.path.join(O, "bench_default_n1.json"), "w").write(json.dumps(bench, indent=1) + "\n")
 
-stats = glob.glob(os.path.join(I, "stats", "*", "*_kernel_stats.csv"))[0]
+newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)      # gpurun merges runs into one directory: take the last one
+stats = newest(os.path.join(I, "stats", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(O, "bench_default_kernel_stats.csv"))
 rows = list(csv.reader(open(stats)))
 with open(os.path.join(O, "bench_default_kernel_stats_lslam.csv"), "w", newline="") as f:
@@ -26,7 +27,7 @@ with open(os.path.join(O, "bench_default_kernel_stats_lslam.csv"), "w", newline=
 
 
 def counters(sub):
-    f = glob.glob(os.path.join(I, sub, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(I, sub, "*", "*_counter_collection.csv"))
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
