@@ -52,6 +52,34 @@ def test_argument_validation_needs_no_gpu():
         icp_batch(pts + 1, off, pts + 1, off, tilt[None])
 
 
+def test_argument_validation_of_the_float64_entry_points_needs_no_gpu():
+    """lslam_icp_batch_f64 / lslam_icp_large_f64 / lslam_host_staging reject bad arguments before any HIP call, with the
+    same status codes (hence the same Python exceptions) as the float32 entry points"""
+    import ctypes as C
+    from lidar_slam_amd import _lib
+    from lidar_slam_amd._lib import lib, ptr
+    from lidar_slam_amd.batch import icp_batch
+    pts = np.zeros((4, 2), dtype=np.float64)
+    off = np.array([0, 4], dtype=np.int64)
+    with pytest.raises(IndexError):
+        icp_batch(pts, off, np.zeros((0, 2)), np.array([0, 0], np.int64), np.eye(4)[None])
+    bad = pts.copy(); bad[1, 0] = np.inf
+    with pytest.raises(ValueError):
+        icp_batch(bad, off, pts, off, np.eye(4)[None])
+    tilt = np.eye(4); tilt[2, 3] = 0.5
+    with pytest.raises(ValueError):
+        icp_batch(pts + 1, off, pts + 1, off, tilt[None])
+    T = np.empty((4, 4)); e = np.empty(1); it = np.empty(1, np.int32)
+    h = lib()
+    assert h.lslam_icp_large_f64(ptr(pts), 4, ptr(pts), 0, 2, ptr(np.eye(4)), 0.01, 1e-4, 10, 0, ptr(T), ptr(e), ptr(it), None, 0) == _lib.ERR_EMPTY_TARGET
+    assert h.lslam_icp_large_f64(ptr(pts), 0, ptr(pts), 4, 2, ptr(np.eye(4)), 0.01, 1e-4, 10, 0, ptr(T), ptr(e), ptr(it), None, 0) == _lib.ERR_BAD_ARG
+    assert h.lslam_icp_large_f64(ptr(bad), 4, ptr(pts), 4, 2, ptr(np.eye(4)), 0.01, 1e-4, 10, 0, ptr(T), ptr(e), ptr(it), None, 0) == _lib.ERR_NONFINITE
+    assert h.lslam_icp_large_f64(ptr(pts), 4, ptr(pts), 4, 5, ptr(np.eye(4)), 0.01, 1e-4, 10, 0, ptr(T), ptr(e), ptr(it), None, 0) == _lib.ERR_BAD_ARG
+    out = C.c_void_p()
+    assert h.lslam_host_staging(2, 64, C.byref(out)) == _lib.ERR_BAD_ARG and b"slot" in h.lslam_last_error()
+    assert h.lslam_host_staging(0, 64, None) == _lib.ERR_BAD_ARG
+
+
 def test_no_silent_cpu_fallback_without_a_device():
     import lidar_slam_amd
     if lidar_slam_amd.device_count() > 0:
