@@ -207,6 +207,11 @@ int lslam_nn_dev(const float *d_src, int64_t n, const float *d_tgt, int64_t m, i
 int lslam_nn(const float *src, int64_t n, const float *tgt, int64_t m, int dim,
              const double *T, int32_t *out_idx, float *out_d2, int device);
 
+/* float64-exact mode of lslam_nn (see lslam_icp_batch_f64): the index a float64 search returns — modules/icp.py:29-41 on the
+ * reference's own float64 points — lowest index on exact float64 ties. */
+int lslam_nn_f64(const double *src, int64_t n, const double *tgt, int64_t m, int dim,
+                 const double *T, int32_t *out_idx, int device);
+
 /* get_transform (icp.py:43-74): Kabsch rigid transform taking rows of p onto rows
  * of q.  p, q: HOST float64, n rows, row strides in doubles (>= 3; the reference
  * passes (N,4) homogeneous arrays and uses [:, 0:3]).  out_T: 16 float64. */

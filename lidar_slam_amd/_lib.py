@@ -68,6 +68,7 @@ SIGNATURES = {
                                   C.c_void_p, C.c_int]),
     "lslam_nn": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_int]),
+    "lslam_nn_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "lslam_nn_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "lslam_kabsch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int]),

@@ -880,6 +880,59 @@ int lslam_nn(const float* src, int64_t n, const float* tgt, int64_t m, int dim, 
   return LSLAM_OK;
 }
 
+// get_correspondences in float64-exact mode: the whole-chip search with the splits' second smallest distances, then the
+// float64-exact moments kernel used for its correspondences only (it decides the near ties on the float64 points)
+int lslam_nn_f64(const double* src, int64_t n, const double* tgt, int64_t m, int dim, const double* T,
+                 int32_t* out_idx, int device) {
+  clear_error();
+  if (dim != 2 && dim != 3) return fail(LSLAM_ERR_BAD_ARG, "dim must be 2 or 3, got %d", dim);
+  if (n < 0) return fail(LSLAM_ERR_BAD_ARG, "negative source size");
+  if (n == 0) return LSLAM_OK;
+  if (!src || !tgt || !out_idx) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (m <= 0) return fail(LSLAM_ERR_EMPTY_TARGET, "empty target cloud");
+  if (n > 0x7fffffff || m > 0x7fffffff) return fail(LSLAM_ERR_BAD_ARG, "clouds above 2^31 points are not supported");
+  if (!all_finite64(src, dim * n) || !all_finite64(tgt, dim * m))
+    return fail(LSLAM_ERR_NONFINITE, "point clouds must be finite (NaN or Inf found)");
+  int rc;
+  if ((rc = use_device(device)) != LSLAM_OK) return rc;
+  Arena& ar = thread_arena();
+  const size_t cs = (size_t)dim * (size_t)n, ct = (size_t)dim * (size_t)m;
+  if ((rc = ar.reserve(device, Arena::align(4 * cs) + Arena::align(4 * ct) + Arena::align(8 * cs) + Arena::align(8 * ct) + Arena::align(4 * (size_t)n))) != LSLAM_OK) return rc;
+  float* d_src = static_cast<float*>(ar.carve(4 * cs));
+  float* d_tgt = static_cast<float*>(ar.carve(4 * ct));
+  double* d_src64 = static_cast<double*>(ar.carve(8 * cs));
+  double* d_tgt64 = static_cast<double*>(ar.carve(8 * ct));
+  int32_t* d_idx = static_cast<int32_t*>(ar.carve(4 * (size_t)n));
+  hipStream_t st;
+  if ((rc = thread_stream(&st)) != LSLAM_OK) return rc;
+  if ((rc = ws_fence().enter(st)) != LSLAM_OK) return rc;
+  LargeWs& ws = large_ws();
+  const NnGeometry geo = nn_geometry(dim, n, m);
+  if ((rc = ws.ensure(device, n * geo.splits)) != LSLAM_OK) return rc;
+  if ((rc = ws.ensure_sec(n * geo.splits)) != LSLAM_OK) return rc;
+  LSLAM_HIP_TRY(hipMemcpyAsync(d_src64, src, 8 * cs, hipMemcpyHostToDevice, st));
+  LSLAM_HIP_TRY(hipMemcpyAsync(d_tgt64, tgt, 8 * ct, hipMemcpyHostToDevice, st));
+  LSLAM_HIP_TRY(launch_f64_to_f32(d_src64, d_src, (int64_t)cs, st));
+  LSLAM_HIP_TRY(launch_f64_to_f32(d_tgt64, d_tgt, (int64_t)ct, st));
+  LSLAM_HIP_TRY(launch_cloud_bounds(d_src, n, d_tgt, m, dim, ws.bounds, st));
+  static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  LargeState* hs = ws.h_state;
+  memcpy(hs->T, T ? T : I4, sizeof(double) * 16);
+  hs->err = 0.0; stop_init(hs->stop); hs->done = 0; hs->ticket = 0;
+  LSLAM_HIP_TRY(hipMemcpyAsync(ws.state, hs, sizeof(LargeState), hipMemcpyHostToDevice, st));
+  NnArgs na{};
+  na.src = d_src; na.n = n; na.tgt = d_tgt; na.m = m; na.keys = ws.keys; na.state = ws.state; na.sec = ws.sec; na.bounds = ws.bounds;
+  LSLAM_HIP_TRY(launch_nn(na, dim, geo, st));
+  MomArgs ma{};
+  ma.src = d_src; ma.n = n; ma.tgt = d_tgt; ma.keys = ws.keys; ma.splits = geo.splits; ma.state = ws.state; ma.partials = ws.partials;
+  ma.out_corr = d_idx; ma.flags = 0; ma.src64 = d_src64; ma.tgt64 = d_tgt64; ma.m = m; ma.sec = ws.sec; ma.bounds = ws.bounds;
+  LSLAM_HIP_TRY(launch_moments(ma, dim, moments_rows(n), st));
+  LSLAM_HIP_TRY(hipMemcpyAsync(out_idx, d_idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+  rc = ws_fence().leave(st);
+  LSLAM_HIP_TRY(hipStreamSynchronize(st));
+  return rc;
+}
+
 // ---------------------------------------------------------------------------------------------------
 static int pair_op(const double* p, int64_t ps, const double* q, int64_t qs, int64_t n, int32_t cols,
                    int32_t normalize, double* out_T, double* out_err, int device) {

@@ -81,10 +81,16 @@ def get_correspondences(pc1, pc2_tree):
     """Index of the nearest target point for every row of pc1 (modules/icp.py:29-41).
     ``pc2_tree`` is a :class:`TargetCloud` (or anything with a ``.data`` array of points, such as
     the ``scipy.spatial.KDTree`` the reference builds)."""
-    tgt = np.ascontiguousarray(np.asarray(pc2_tree.data)[:, :3], dtype=np.float32)
-    src = np.ascontiguousarray(_xyz(pc1), dtype=np.float32)
-    out = np.empty(src.shape[0], dtype=np.int32)
-    check(lib().lslam_nn(ptr(src), src.shape[0], ptr(tgt), tgt.shape[0], 3, None, ptr(out), None, _DEVICE))
+    data, pc1 = np.asarray(pc2_tree.data), np.asarray(pc1)
+    out = np.empty(pc1.shape[0], dtype=np.int32)
+    if data.dtype == np.float32 and pc1.dtype == np.float32:      # float32 points: searched as they are
+        tgt = np.ascontiguousarray(data[:, :3], dtype=np.float32)
+        src = np.ascontiguousarray(_xyz(pc1), dtype=np.float32)
+        check(lib().lslam_nn(ptr(src), src.shape[0], ptr(tgt), tgt.shape[0], 3, None, ptr(out), None, _DEVICE))
+    else:                                                         # the reference's type: float64-exact mode
+        tgt = np.ascontiguousarray(data[:, :3], dtype=np.float64)
+        src = np.ascontiguousarray(_xyz(pc1), dtype=np.float64)
+        check(lib().lslam_nn_f64(ptr(src), src.shape[0], ptr(tgt), tgt.shape[0], 3, None, ptr(out), _DEVICE))
     return out.astype(np.int64)
 
 

@@ -219,6 +219,30 @@ def test_clouds_far_from_the_origin_are_centred_before_rounding(icp, prec):
     assert np.abs(T[:3, :3] - o.T[:3, :3]).max() < TOL_ROT
 
 
+def test_get_correspondences_in_both_precisions(icp, prec):
+    """modules/icp.py:29-41: float64 points -> the float64 search's indices (duplicates: lowest index; near ties decided in
+    float64), float32 points -> the exact float32 recipe; 3-D and planar-padded, a target at the rim of float32 resolution"""
+    from oracle import c_oracle, icp_oracle
+    rng = np.random.default_rng(17)
+    tgt = rng.uniform(-30, 30, (6000, 3))
+    src = tgt[rng.integers(0, 6000, 2500)] + rng.normal(0, 0.02, (2500, 3))
+    tgt[4000:4010] = tgt[20:30]                                   # exact duplicates: the lowest index must win
+    # two targets whose distances to a source differ by less than float32 can tell: in float32 an exact tie (lowest index, 100),
+    # in float64 the second one is nearer by 3 nm
+    src[5] = [100.0, 100.0, 100.0]
+    tgt[100] = src[5] + np.array([0.25 + 3e-9, 0.0, 0.0]); tgt[101] = src[5] - np.array([0.25, 0.0, 0.0])
+    s, t = prec.cast(src), prec.cast(tgt)
+    idx = icp.get_correspondences(s, icp.TargetCloud(t))
+    assert idx.dtype == np.int64
+    if prec.name == "f32":
+        ref, _ = c_oracle.nn_f32(s, t)
+        assert idx[5] == 100
+    else:
+        ref = icp_oracle.nn_bruteforce(src, tgt)
+        assert idx[5] == 101
+    np.testing.assert_array_equal(idx, ref)
+
+
 def test_get_transform_get_error_get_correspondences(icp, prec):
     if prec.name == "f64":
         pytest.skip("these operators have one precision")
