@@ -979,3 +979,47 @@ def test_filter_bound_with_sources_far_from_a_target_at_the_origin(icp, dim, mon
     assert it[0] == ito == 1
     np.testing.assert_array_equal(corr, co)
     np.testing.assert_allclose(err[0], eo, rtol=1e-9)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_float64_exact_mode_on_clouds_made_of_near_ties(icp, dim, monkeypatch, prec):
+    """the worst case for float64-exact mode: targets on a lattice moved by 1e-9 … 1e-6 (far below float32 resolution at these
+    coordinates), sources at the cell centres moved likewise — EVERY source has 2^dim candidates the float32 search cannot tell
+    apart, spread over several chunks, and the float64 winner is decided by the nanometre perturbations.  All batched kernels
+    (all pairs: small / big / filter builds; pruned), the co-resident kernel and both whole-chip paths against the C oracle's
+    float64 recipe.  (float32 clouds: the same data rounded — massive exact ties, lowest index — against the device recipe.)"""
+    from lidar_slam_amd import _lib
+    from lidar_slam_amd._lib import check, lib, ptr
+    from lidar_slam_amd.batch import icp_batch
+    from oracle import c_oracle
+    rng = np.random.default_rng(4242 + dim)
+    side = 40 if dim == 2 else 12
+    g = np.stack(np.meshgrid(*([np.arange(side)] * dim)), -1).reshape(-1, dim) * 0.5 + 7.0          # coordinates 7 … 27: float32 ulp ≈ 1e-6
+    cases = []
+    for scale in (1e-9, 1e-7, 1e-6):
+        t = g[rng.permutation(g.shape[0])] + rng.uniform(-1, 1, g.shape) * scale
+        s = g[rng.integers(0, g.shape[0], 900)] + 0.25 + rng.uniform(-1, 1, (900, dim)) * scale
+        cases.append((s, t))
+    fs, so = prec.pack([c[0] for c in cases]); ft, to = prec.pack([c[1] for c in cases])
+    I = np.tile(np.eye(4), (len(cases), 1, 1))
+    kw = dict(epsilon=0.0, stopping_thresh=0.0, max_iters=1, return_correspondences=True)
+    oracles = [c_oracle.run_icp(s, t, np.eye(4), epsilon=0.0, stopping_thresh=0.0, max_iters=1, recipe=prec.recipe) for s, t in cases]
+    for prune, variant in ((False, None), (False, "1"), (True, None)):
+        if variant:
+            monkeypatch.setenv("LSLAM_ICP_VARIANT", variant)
+        r = icp_batch(fs, so, ft, to, I, prune=prune, **kw)
+        monkeypatch.delenv("LSLAM_ICP_VARIANT", raising=False)
+        for k, (To, eo, co, ito) in enumerate(oracles):
+            assert r.iterations[k] == ito == 2
+            np.testing.assert_array_equal(r.correspondences[so[k]:so[k + 1]], co, err_msg=f"prune={prune} variant={variant} case {k}")
+            np.testing.assert_allclose(r.T[k], To, atol=1e-9)
+    entry = lib().lslam_icp_large_f64 if prec.name == "f64" else lib().lslam_icp_large
+    for k, (s, t) in enumerate(cases):
+        sc, tc = prec.cast(s), prec.cast(t)
+        for flags, coop in ((_lib.ICP_ALL_PAIRS, "1"), (_lib.ICP_ALL_PAIRS, "0"), (_lib.ICP_PRUNE, "1")):
+            monkeypatch.setenv("LSLAM_ICP_COOP", coop)
+            T = np.empty((4, 4)); err = np.empty(1); it = np.empty(1, np.int32); corr = np.empty(s.shape[0], np.int32)
+            check(entry(ptr(sc), s.shape[0], ptr(tc), t.shape[0], dim, ptr(np.eye(4)), 0.0, 0.0, 1, flags, ptr(T), ptr(err), ptr(it), ptr(corr), 0))
+            assert it[0] == 2
+            np.testing.assert_array_equal(corr, oracles[k][2], err_msg=f"whole-chip flags={flags} coop={coop} case {k}")
+            np.testing.assert_allclose(T, oracles[k][0], atol=1e-9)
