@@ -252,12 +252,20 @@ icp_coop_kernel(CoopArgs a) {
     if (wave == 0) {
       unsigned long long kmin = ~0ull;
       float v1 = INFINITY, v2 = INFINITY;
-      for (int s = sub; s < NS; s += SUB) {
-        const unsigned long long k = skey[s * SPW + sl];
-        kmin = k < kmin ? k : kmin;
-        const float b = __uint_as_float((unsigned)(k >> 32)), sc = ssec[s * SPW + sl];
-        v2 = __builtin_amdgcn_fmed3f(v1, v2, b); v1 = fminf(v1, b);
-        v2 = __builtin_amdgcn_fmed3f(v1, v2, sc); v1 = fminf(v1, sc);
+      {
+        // all 16 loads first, then the fold: issued one by one behind the fold's dependency each load costs a full LDS round trip
+        unsigned long long ks[kCoopWaves];
+        float scs[kCoopWaves];
+#pragma unroll
+        for (int u = 0; u < kCoopWaves; ++u) { ks[u] = skey[(sub + u * SUB) * SPW + sl]; scs[u] = ssec[(sub + u * SUB) * SPW + sl]; }
+#pragma unroll
+        for (int u = 0; u < kCoopWaves; ++u) {
+          const unsigned long long k = ks[u];
+          kmin = k < kmin ? k : kmin;
+          const float b = __uint_as_float((unsigned)(k >> 32)), sc = scs[u];
+          v2 = __builtin_amdgcn_fmed3f(v1, v2, b); v1 = fminf(v1, b);
+          v2 = __builtin_amdgcn_fmed3f(v1, v2, sc); v1 = fminf(v1, sc);
+        }
       }
 #pragma unroll
       for (int o = SPW; o < 64; o <<= 1) {             // lanes sl, sl + SPW, … hold the same source
@@ -373,16 +381,25 @@ icp_coop_kernel(CoopArgs a) {
         if (v < nvals) sred[v * 65 + lane] = vals[v];
       const int rv = lane % VP, rg = lane / VP;
       double tot = 0.0;
-      if (rv < nvals) {
-        const double* row = sred + rv * 65 + rg * (64 / NSEG);
-        tot = row[0];
-        for (int k = 1; k < 64 / NSEG; ++k) tot = (rv < kSums) ? tot + row[k] : ((rv < kSums + DIM) ? fmin(tot, row[k]) : fmax(tot, row[k]));
+      const bool is_sum = rv < kSums, is_min = rv < kSums + DIM;
+      // sum / min / max chosen with selects, not branches: the loads of a rolled, branchy loop are issued one LDS round trip at a time
+      // (without the bounding box every value is a sum: a wave-uniform case, float64 min / max are slow instructions)
+      auto fold = [&](double acc_, double x_) {
+        if (!box) return acc_ + x_;
+        const double s_ = acc_ + x_, lo_ = fmin(acc_, x_), hi_ = fmax(acc_, x_);
+        return is_sum ? s_ : (is_min ? lo_ : hi_);
+      };
+      {
+        const double* row = sred + (rv < nvals ? rv : 0) * 65 + rg * (64 / NSEG);
+        double xs[64 / NSEG];
+#pragma unroll
+        for (int k = 0; k < 64 / NSEG; ++k) xs[k] = row[k];
+        tot = xs[0];
+#pragma unroll
+        for (int k = 1; k < 64 / NSEG; ++k) tot = fold(tot, xs[k]);
       }
 #pragma unroll
-      for (int o = VP; o < 64; o <<= 1) {
-        const double other = __shfl_xor(tot, o, 64);
-        tot = (rv < kSums) ? tot + other : ((rv < kSums + DIM) ? fmin(tot, other) : fmax(tot, other));
-      }
+      for (int o = VP; o < 64; o <<= 1) tot = fold(tot, __shfl_xor(tot, o, 64));
       COOP_MARK(3);
       // publish: lane v < nvals owns value v
       typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -422,22 +439,32 @@ icp_coop_kernel(CoopArgs a) {
           for (int half = 0; half < (VP == 32 ? 2 : 1); ++half) {          // 3-D rows have up to 22 values: lanes take v and v + 16
             const int v = cv + 16 * half;
             if (v >= nvals) continue;
-            double acc = 0.0;
-            bool first = true;
-            for (int w = qr; w < G; w += 4) {
-              const unsigned lo = rows32[(w * kVals + v) * 2], hi = rows32[(w * kVals + v) * 2 + 1];
-              const double x = __hiloint2double((int)hi, (int)lo);
-              acc = first ? x : ((v < kSums) ? acc + x : ((v < kSums + DIM) ? fmin(acc, x) : fmax(acc, x)));
-              first = false;
+            // a quarter without a workgroup holds the neutral element; four rows per trip, their loads issued together
+            const bool vsum = v < kSums, vmin = v < kSums + DIM;
+            const double neutral = vsum ? 0.0 : (vmin ? INFINITY : -INFINITY);
+            double acc = neutral;
+            for (int w0 = qr; w0 < G; w0 += 16) {
+              unsigned lo[4], hi[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int w = w0 + 4 * u, wc = w < G ? w : qr;                 // clamped: a valid row, ignored below
+                lo[u] = rows32[(wc * kVals + v) * 2]; hi[u] = rows32[(wc * kVals + v) * 2 + 1];
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const double x = (w0 + 4 * u < G) ? __hiloint2double((int)hi[u], (int)lo[u]) : neutral;
+                if (!box) { acc += x; continue; }                               // wave-uniform: sums only
+                const double s_ = acc + x, lo_ = fmin(acc, x), hi_ = fmax(acc, x);
+                acc = vsum ? s_ : (vmin ? lo_ : hi_);
+              }
             }
-            // fold the four quarters (lanes cv, cv + 16, cv + 32, cv + 48); a quarter without a workgroup holds the neutral element
-            if (first) acc = (v < kSums) ? 0.0 : ((v < kSums + DIM) ? INFINITY : -INFINITY);
             sred[(v * 4 + qr)] = acc;
           }
         }
         if (lane < nvals) {
           const double q0 = sred[lane * 4], q1 = sred[lane * 4 + 1], q2 = sred[lane * 4 + 2], q3 = sred[lane * 4 + 3];
-          col = (lane < kSums) ? ((q0 + q1) + (q2 + q3)) : ((lane < kSums + DIM) ? fmin(fmin(q0, q1), fmin(q2, q3)) : fmax(fmax(q0, q1), fmax(q2, q3)));
+          if (!box) col = (q0 + q1) + (q2 + q3);
+          else col = (lane < kSums) ? ((q0 + q1) + (q2 + q3)) : ((lane < kSums + DIM) ? fmin(fmin(q0, q1), fmin(q2, q3)) : fmax(fmax(q0, q1), fmax(q2, q3)));
         }
       }
       Moments mo;

@@ -459,11 +459,22 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
     if (wave == 0) {
       constexpr int kS = AccLayout<2>::kSums;
       double col = 0.0;
-      if (lane < kAcc) {
-        col = sh_red[lane];
-        for (int w = 1; w < nwaves; ++w) {
-          const double v = sh_red[(size_t)w * kAcc + lane];
-          col = (lane < kS) ? col + v : ((lane < kS + 2) ? fmin(col, v) : fmax(col, v));
+      {
+        // four rows per trip, their loads issued together, sum / min / max chosen with selects: as a rolled loop with a branch
+        // per row every load waited for a full LDS round trip (up to 16 per iteration of every problem)
+        const int cl = lane < kAcc ? lane : 0;
+        const bool is_sum = lane < kS, is_min = lane < kS + 2;
+        col = sh_red[cl];
+        for (int w0 = 1; w0 < nwaves; w0 += 4) {
+          double x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) x[u] = sh_red[(size_t)(w0 + u < nwaves ? w0 + u : 0) * kAcc + cl];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (!box) { col = (w0 + u < nwaves) ? col + x[u] : col; continue; }      // wave-uniform: without the bounding box every value is a sum
+            const double s_ = col + x[u], lo_ = fmin(col, x[u]), hi_ = fmax(col, x[u]);
+            col = (w0 + u < nwaves) ? (is_sum ? s_ : (is_min ? lo_ : hi_)) : col;
+          }
         }
       }
       double tot[kAcc];
