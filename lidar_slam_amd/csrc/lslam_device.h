@@ -162,17 +162,25 @@ __device__ __forceinline__ void filter_eval4(const FilterRegsPlanar4& r, const f
   }
 }
 
-// the three smallest chunk minima b1 ≤ b2 ≤ b3 and the chunk ids of the first two, updated with chunk c's minimum
-__device__ __forceinline__ void filter_track(float mc, int c, float& b1, float& b2, float& b3, int& i1, int& i2) {
-  // selects, not branches (the conditions are data-dependent per lane)
-  const bool lt1 = __builtin_unpredictable(mc < b1), lt2 = __builtin_unpredictable(mc < b2);
-  b3 = __builtin_amdgcn_fmed3f(b2, b3, mc);                  // b2 ≤ b3 holds: the median is the new third smallest
-  b2 = __builtin_amdgcn_fmed3f(b1, b2, mc);
-  b1 = lt1 ? mc : b1;
-  const int i2n = lt2 ? c : i2;
-  i2 = lt1 ? i1 : i2n;
-  i1 = lt1 ? c : i1;
+// The three smallest chunk minima, each carrying its chunk id — updated with chunk c's minimum mc (c < 256).
+// Tracked is  s = mc + |a|²  (≈ the squared distance to the chunk's best target: small and of either sign by at most the
+// filter's error E, where mc itself is ≈ −|a|²) with the chunk id written into its 8 low mantissa bits.  The id then rides
+// along through v_med3 / v_min for free: 14 issue cycles per chunk and point instead of 22 for values and ids kept apart
+// (2 v_cmp, 2 half-rate v_med3, 5 v_cndmask) — 11.5 % of the headline kernel's cycles went there.  What the 8 bits cost: every
+// tracked value is off by < 2⁻¹⁵ of ITS OWN magnitude (|s| ≈ d², not |a|²): filter_decide adds that to its window.  The same
+// a2 is added to every chunk minimum of a point, so its own rounding shifts all of them alike.
+constexpr int kFilterIdBits = 8;
+__device__ __forceinline__ void filter_track(float mc, float a2, int c, float& s1, float& s2, float& s3) {
+  // written as instructions: from C++ the compiler splits the and-or in two and, because s comes out of integer
+  // operations, guards fminf with two canonicalising v_max (8 instead of 5 instructions per point)
+  float s;
+  const float sum = mc + a2;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(s) : "v"(sum), "v"(~((1u << kFilterIdBits) - 1u)), "s"(c));      // one scalar operand only (constant bus)
+  s3 = __builtin_amdgcn_fmed3f(s2, s3, s);                   // s2 ≤ s3 holds: the median is the new third smallest
+  s2 = __builtin_amdgcn_fmed3f(s1, s2, s);
+  asm("v_min_f32 %0, %1, %2" : "=v"(s1) : "v"(s1), "v"(s));
 }
+__device__ __forceinline__ int filter_chunk_of(float s) { return (int)(__float_as_uint(s) & ((1u << kFilterIdBits) - 1u)); }
 
 // ---- float64-exact mode: near ties of the float32 search are decided in float64 ---------------------
 // The reference searches in float64 (modules/icp.py:29-41).  When the caller also hands over the float64 clouds, the
@@ -214,22 +222,26 @@ __device__ __forceinline__ float near_lim(float D, const NearTie& nt) {
 // target within lim(D̂) of the winner, not only the winner: τ grows by lim(d²) − d² (+ 2u·d² for the roundings of lim's
 // argument), see DESIGN.md §3.1d.
 template <int DIM>
-__device__ __forceinline__ void filter_decide(const float (&a)[DIM], float Rt, float b1, float b2, float b3, const NearTie& nt, bool& two, bool& third) {
+__device__ __forceinline__ void filter_decide(const float (&a)[DIM], float Rt, float s1, float s2, float s3, const NearTie& nt, bool& two, bool& third) {
   constexpr float kU = 5.97e-8f;                             // > 2⁻²⁴
   constexpr float kE = (DIM == 2 ? 4.5f : 6.5f) * kU;
   // the direct recipe rounds the x term four times in the plane (|θ| ≤ 4.01u), five times in space (5.01u): 2θ + margins
   constexpr float kD = (DIM == 2 ? 9.f : 11.f) * kU;
+  constexpr float kId = 3.1e-5f;                             // > 2⁻¹⁵: what the chunk id in the low mantissa bits moves a tracked value by (relative)
   float a2;
   if constexpr (DIM == 2) a2 = __builtin_fmaf(a[1], a[1], a[0] * a[0]);
   else a2 = __builtin_fmaf(a[2], a[2], __builtin_fmaf(a[1], a[1], a[0] * a[0]));
   const float an = sqrtf(a2) * 1.0001f;
   const float E = kE * Rt * (Rt + an);
-  const float d2 = fmaxf((b1 + a2) * 1.000001f + E + 3.f * kU * a2, 0.f);       // ≥ |a − t|² of the filter's winner
+  // s1 ≈ (smallest filter value) + |a|²: ≥ |a − t|² of the filter's winner once the slack terms are added
+  const float d2 = fmaxf(s1 * (1.f + 2.f * kId) + fabsf(s1) * kId + E + 3.f * kU * a2, 0.f);
   float tau = (2.f * E + kD * d2) * 1.001f + 1e-30f;
   if (nt.on) tau += (near_lim(d2, nt) - d2) * 1.0001f + 2.f * kU * d2;
-  const float lim = b1 + tau;
-  two = !(b2 > lim);
-  third = !(b3 > lim) || !(Rt < 1e15f) || !(an < 1e15f);
+  // both sides of the comparison carry an id: each is off by ≤ kId of its own magnitude, and everything compared lies within
+  // |s1| + tau of zero
+  const float lim = s1 + tau + 2.f * kId * (fabsf(s1) + tau);
+  two = !(s2 > lim);
+  third = !(s3 > lim) || !(Rt < 1e15f) || !(an < 1e15f);
 }
 
 // Accumulator slots of one (p, q) pair stream, in the order they are reduced.

@@ -130,8 +130,7 @@ __device__ __forceinline__ void sweep_tile(const typename TilePoint<DIM>::type* 
 // its use — two register buffers held apart with scheduling barriers — was measured: no gain, 24 more VGPRs.)
 template <int DIM, int P>
 __device__ __forceinline__ void filter_sweep(const typename TilePoint<DIM>::type* tile, const float* wt, int nchunks,
-                                             const float (&na)[P][DIM], float (&b1)[P], float (&b2)[P], float (&b3)[P],
-                                             int (&i1)[P], int (&i2)[P]) {
+                                             const float (&na)[P][DIM], const float (&a2)[P], float (&b1)[P], float (&b2)[P], float (&b3)[P]) {
   constexpr int kGroups = kFilterChunk / kFilterStep;          // 4 load groups per chunk
   for (int c = 0; c < nchunks; ++c) {
     float m[P];
@@ -154,7 +153,7 @@ __device__ __forceinline__ void filter_sweep(const typename TilePoint<DIM>::type
       }
     }
 #pragma unroll
-    for (int p = 0; p < P; ++p) filter_track(m[p], c, b1[p], b2[p], b3[p], i1[p], i2[p]);
+    for (int p = 0; p < P; ++p) filter_track(m[p], a2[p], c, b1[p], b2[p], b3[p]);
   }
 }
 
@@ -376,15 +375,19 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
       // the filter is dropped for this wave once it fell back in at least half of its attempts (lattices, clouds far
       // from the origin): from then on the exact sweep runs directly
       if (resident && wave_live && 2 * f_fails < f_tries + 1) {
-        float b1[P], b2[P], b3[P], na[P][DIM];
+        float b1[P], b2[P], b3[P], na[P][DIM], a2[P];        // b: the three smallest (chunk minimum + |a|²), chunk id in the low mantissa bits
         int i1[P], i2[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          b1[p] = b2[p] = b3[p] = INFINITY; i1[p] = 0; i2[p] = 0;
+          b1[p] = b2[p] = b3[p] = INFINITY;
 #pragma unroll
           for (int r = 0; r < DIM; ++r) na[p][r] = -2.f * a[p][r];
+          if constexpr (DIM == 2) a2[p] = __builtin_fmaf(a[p][1], a[p][1], a[p][0] * a[p][0]);
+          else a2[p] = __builtin_fmaf(a[p][2], a[p][2], __builtin_fmaf(a[p][1], a[p][1], a[p][0] * a[p][0]));
         }
-        filter_sweep<DIM, P>(tile, wtile, m_padded / kFilterChunk, na, b1, b2, b3, i1, i2);
+        filter_sweep<DIM, P>(tile, wtile, m_padded / kFilterChunk, na, a2, b1, b2, b3);
+#pragma unroll
+        for (int p = 0; p < P; ++p) { i1[p] = filter_chunk_of(b1[p]); i2[p] = filter_chunk_of(b2[p]); }
         // a = −na/2 exactly: re-deriving it here keeps `a` out of the registers that are live across the sweep
 #pragma unroll
         for (int p = 0; p < P; ++p)

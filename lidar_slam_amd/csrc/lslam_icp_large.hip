@@ -337,10 +337,15 @@ nn_tiled_filter_kernel(NnArgs a) {
   for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
   if (lane == 0) atomicMax(&sh_wmax, __float_as_int(wmax));   // non-negative floats order like their bits
 
-  float b1[P], b2[P], b3[P];
+  float b1[P], b2[P], b3[P], a2[P];                           // b: the three smallest (chunk minimum + |a|²), chunk id in the low mantissa bits
   int i1[P], i2[P];
 #pragma unroll
-  for (int p = 0; p < P; ++p) { b1[p] = b2[p] = b3[p] = INFINITY; i1[p] = 0; i2[p] = 0; }
+  for (int p = 0; p < P; ++p) {
+    b1[p] = b2[p] = b3[p] = INFINITY;
+    // |a|² from a = −na/2 (exact), in the operation order filter_decide uses
+    if constexpr (DIM == 2) a2[p] = __builtin_fmaf(-0.5f * na[p][1], -0.5f * na[p][1], (-0.5f * na[p][0]) * (-0.5f * na[p][0]));
+    else a2[p] = __builtin_fmaf(-0.5f * na[p][2], -0.5f * na[p][2], __builtin_fmaf(-0.5f * na[p][1], -0.5f * na[p][1], (-0.5f * na[p][0]) * (-0.5f * na[p][0])));
+  }
   for (int c = 0; c < padded / FCH; ++c) {
     float m[P];
 #pragma unroll
@@ -352,8 +357,10 @@ nn_tiled_filter_kernel(NnArgs a) {
       filter_eval<DIM, P>(A, na, m);
     }
 #pragma unroll
-    for (int p = 0; p < P; ++p) filter_track(m[p], c, b1[p], b2[p], b3[p], i1[p], i2[p]);
+    for (int p = 0; p < P; ++p) filter_track(m[p], a2[p], c, b1[p], b2[p], b3[p]);
   }
+#pragma unroll
+  for (int p = 0; p < P; ++p) { i1[p] = filter_chunk_of(b1[p]); i2[p] = filter_chunk_of(b2[p]); }
   __syncthreads();                                            // every wave's maximum is in
   const float Rt = sqrtf(__int_as_float(sh_wmax)) * 1.0001f;
 
