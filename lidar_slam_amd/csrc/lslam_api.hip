@@ -232,12 +232,25 @@ static int icp_batch_dev_impl(const float* d_src, const double* d_src64, const i
       if (sc3.src_index) (void)hipFree(sc3.src_index);
       if (sc3.tgt_sorted) (void)hipFree(sc3.tgt_sorted);
       if (sc3.tgt_index) (void)hipFree(sc3.tgt_index);
+      if (sc3.src64_sorted) (void)hipFree(sc3.src64_sorted);
+      if (sc3.tgt64_sorted) (void)hipFree(sc3.tgt64_sorted);
       sc3 = PruneScratch3{}; cap3_src = cap3_tgt = 0; sc3_dev = dev;
       LSLAM_HIP_TRY(hipMalloc(&sc3.src_sorted, sizeof(float4) * need_src));
       LSLAM_HIP_TRY(hipMalloc(&sc3.src_index, sizeof(uint16_t) * need_src));
       LSLAM_HIP_TRY(hipMalloc(&sc3.tgt_sorted, sizeof(float4) * need_tgt));
       LSLAM_HIP_TRY(hipMalloc(&sc3.tgt_index, sizeof(uint16_t) * need_tgt));
       cap3_src = need_src; cap3_tgt = need_tgt;
+    }
+    // float64-exact mode: the float64 clouds in sorted order as well (allocated on first use, sized like the others)
+    static thread_local size_t cap3_src64 = 0, cap3_tgt64 = 0;
+    if (d_src64 && (dev != sc3_dev || need_src > cap3_src64 || need_tgt > cap3_tgt64 || !sc3.src64_sorted)) {
+      LSLAM_HIP_TRY(hipDeviceSynchronize());
+      if (sc3.src64_sorted) (void)hipFree(sc3.src64_sorted);
+      if (sc3.tgt64_sorted) (void)hipFree(sc3.tgt64_sorted);
+      sc3.src64_sorted = nullptr; sc3.tgt64_sorted = nullptr; cap3_src64 = cap3_tgt64 = 0;
+      LSLAM_HIP_TRY(hipMalloc(&sc3.src64_sorted, sizeof(double) * 3 * need_src));
+      LSLAM_HIP_TRY(hipMalloc(&sc3.tgt64_sorted, sizeof(double) * 3 * need_tgt));
+      cap3_src64 = need_src; cap3_tgt64 = need_tgt;
     }
     sc3.src_stride = max_src_n; sc3.tgt_stride = max_tgt_n;
     LSLAM_HIP_TRY(launch_icp_pruned3(a, sc3, S, max_src_n, max_tgt_n, static_cast<hipStream_t>(stream)));
@@ -257,12 +270,24 @@ static int icp_batch_dev_impl(const float* d_src, const double* d_src64, const i
       if (sc.src_index) (void)hipFree(sc.src_index);
       if (sc.tgt_sorted) (void)hipFree(sc.tgt_sorted);
       if (sc.tgt_index) (void)hipFree(sc.tgt_index);
+      if (sc.src64_sorted) (void)hipFree(sc.src64_sorted);
+      if (sc.tgt64_sorted) (void)hipFree(sc.tgt64_sorted);
       sc = PruneScratch{}; cap_src = cap_tgt = 0; sc_dev = dev;
       LSLAM_HIP_TRY(hipMalloc(&sc.src_sorted, sizeof(float2) * need_src));
       LSLAM_HIP_TRY(hipMalloc(&sc.src_index, sizeof(uint16_t) * need_src));
       LSLAM_HIP_TRY(hipMalloc(&sc.tgt_sorted, sizeof(float2) * need_tgt));
       LSLAM_HIP_TRY(hipMalloc(&sc.tgt_index, sizeof(uint16_t) * need_tgt));
       cap_src = need_src; cap_tgt = need_tgt;
+    }
+    static thread_local size_t cap_src64 = 0, cap_tgt64 = 0;
+    if (d_src64 && (need_src > cap_src64 || need_tgt > cap_tgt64 || !sc.src64_sorted)) {
+      LSLAM_HIP_TRY(hipDeviceSynchronize());
+      if (sc.src64_sorted) (void)hipFree(sc.src64_sorted);
+      if (sc.tgt64_sorted) (void)hipFree(sc.tgt64_sorted);
+      sc.src64_sorted = nullptr; sc.tgt64_sorted = nullptr; cap_src64 = cap_tgt64 = 0;
+      LSLAM_HIP_TRY(hipMalloc(&sc.src64_sorted, sizeof(double2) * need_src));
+      LSLAM_HIP_TRY(hipMalloc(&sc.tgt64_sorted, sizeof(double2) * need_tgt));
+      cap_src64 = need_src; cap_tgt64 = need_tgt;
     }
     sc.src_stride = max_src_n; sc.tgt_stride = max_tgt_n;
     LSLAM_HIP_TRY(launch_icp_pruned(a, sc, S, max_src_n, max_tgt_n, static_cast<hipStream_t>(stream)));

@@ -121,6 +121,7 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2) {
     const unsigned o = keys[j] & 8191u;
     sc.tgt_sorted[ts + j] = tgt[o];
     sc.tgt_index[ts + j] = (uint16_t)o;
+    if (a.tgt64) sc.tgt64_sorted[ts + j] = reinterpret_cast<const double2*>(a.tgt64)[t0 + o];
   }
   __syncthreads();
   // ---- source, placed by its initial transform into the target's grid ----
@@ -139,6 +140,7 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2) {
     const unsigned o = keys[i] & 8191u;
     sc.src_sorted[ss + i] = src[o];
     sc.src_index[ss + i] = (uint16_t)o;
+    if (a.src64) sc.src64_sorted[ss + i] = reinterpret_cast<const double2*>(a.src64)[s0 + o];
   }
 }
 
@@ -173,9 +175,8 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   const bool box = (args.flags & kFlagNormalize) != 0;
   const int nchunks = (m + CHUNK - 1) / CHUNK;
 
-  const double* __restrict__ gsrc64 = F64 ? args.src64 + 2 * s0 : nullptr;          // original order, like args.src
-  const double* __restrict__ gtgt64 = F64 ? args.tgt64 + 2 * t0 : nullptr;
-  const uint16_t* __restrict__ sidx = sc.src_index + ss;     // original index of a sorted source
+  const double2* __restrict__ gsrc64 = F64 ? sc.src64_sorted + ss : nullptr;        // the float64 clouds in the SORTED order (icp_sort_kernel)
+  const double2* __restrict__ gtgt64 = F64 ? sc.tgt64_sorted + ts : nullptr;
   if (tid < 16) sh_T[tid] = args.init_T[(int64_t)16 * pair + tid];
   if (F64 && tid == 0) { sh_flag[1] = 0; sh_flag[2] = 0; }   // bits of max |t|², max |p|²
   float tmax = 0.f, smax = 0.f;
@@ -375,8 +376,8 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
             const float lim = near[p] ? near_lim(bd[p], nt) : -INFINITY;
             double adx = 0.0, ady = 0.0;
             if (near[p]) {
-              const int o = sidx[i];
-              const double x = gsrc64[2 * o], y = gsrc64[2 * o + 1];
+              const double2 pd = gsrc64[i];
+              const double x = pd.x, y = pd.y;
               adx = T[0][0] * x + T[0][1] * y + T[0][3];       // icp.py:116 on the float64 point
               ady = T[1][0] * x + T[1][1] * y + T[1][3];
             }
@@ -392,7 +393,8 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
                 const float2 q = tile[j];
                 if (dist2(ax[p], ay[p], q.x, q.y) <= lim) {    // rare: a candidate of this lane (padding is at +inf)
                   const int o = tidx[j];
-                  const double dx = adx - gtgt64[2 * o], dy = ady - gtgt64[2 * o + 1];
+                  const double2 td = gtgt64[j];
+                  const double dx = adx - td.x, dy = ady - td.y;
                   const double e = dx * dx + dy * dy;
                   if (e < bv || (e == bv && o < bo)) { bv = e; bo = o; bp = j; }
                 }
@@ -437,9 +439,9 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
           const int ps = sh_prev[i];
           double x, y, pd[2], qd[2];
           if constexpr (F64) {                                // the float64 points themselves (original order)
-            const int so = sidx[i], to = tidx[ps];
-            x = gsrc64[2 * so]; y = gsrc64[2 * so + 1];
-            qd[0] = gtgt64[2 * to]; qd[1] = gtgt64[2 * to + 1];
+            const double2 pd = gsrc64[i], td = gtgt64[ps];
+            x = pd.x; y = pd.y;
+            qd[0] = td.x; qd[1] = td.y;
           } else {
             const float2 v = src_lds ? sh_src[i] : ssrc[i];
             const float2 q = tile[ps];

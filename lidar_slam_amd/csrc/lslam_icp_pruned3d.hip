@@ -114,6 +114,8 @@ icp_sort3_kernel(IcpBatchArgs a, PruneScratch3 sc, int len_pow2) {
     const unsigned o = keys[j] & 8191u;
     sc.tgt_sorted[ts + j] = make_float4(tgt[3 * o], tgt[3 * o + 1], tgt[3 * o + 2], 0.f);
     sc.tgt_index[ts + j] = (uint16_t)o;
+    if (a.tgt64)
+      for (int r = 0; r < 3; ++r) sc.tgt64_sorted[3 * (ts + j) + r] = a.tgt64[3 * (t0 + o) + r];
   }
   __syncthreads();
   // ---- source, placed by its initial transform into the target's grid ----
@@ -137,6 +139,8 @@ icp_sort3_kernel(IcpBatchArgs a, PruneScratch3 sc, int len_pow2) {
     const unsigned o = keys[i] & 8191u;
     sc.src_sorted[ss + i] = make_float4(src[3 * o], src[3 * o + 1], src[3 * o + 2], 0.f);
     sc.src_index[ss + i] = (uint16_t)o;
+    if (a.src64)
+      for (int r = 0; r < 3; ++r) sc.src64_sorted[3 * (ss + i) + r] = a.src64[3 * (s0 + o) + r];
   }
 }
 
@@ -167,9 +171,8 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
   const bool box = (args.flags & kFlagNormalize) != 0;
   const int nchunks = (m + CHUNK - 1) / CHUNK;
 
-  const double* __restrict__ gsrc64 = F64 ? args.src64 + 3 * s0 : nullptr;          // original order, like args.src
-  const double* __restrict__ gtgt64 = F64 ? args.tgt64 + 3 * t0 : nullptr;
-  const uint16_t* __restrict__ sidx = sc.src_index + ss;     // original index of a sorted source
+  const double* __restrict__ gsrc64 = F64 ? sc.src64_sorted + 3 * ss : nullptr;     // the float64 clouds in the SORTED order (icp_sort3_kernel)
+  const double* __restrict__ gtgt64 = F64 ? sc.tgt64_sorted + 3 * ts : nullptr;
   if (tid < 16) sh_T[tid] = args.init_T[(int64_t)16 * pair + tid];
   if (F64 && tid == 0) { sh_flag[1] = 0; sh_flag[2] = 0; }   // bits of max |t|², max |p|²
   float tmax = 0.f, smax = 0.f;
@@ -353,8 +356,7 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
             const float lim = near[p] ? near_lim(bd[p], nt) : -INFINITY;
             double ad[3] = {0.0, 0.0, 0.0};
             if (near[p]) {
-              const int o = sidx[i];
-              const double x = gsrc64[3 * o], y = gsrc64[3 * o + 1], z = gsrc64[3 * o + 2];
+              const double x = gsrc64[3 * i], y = gsrc64[3 * i + 1], z = gsrc64[3 * i + 2];
 #pragma unroll
               for (int r = 0; r < 3; ++r) ad[r] = T[r][0] * x + T[r][1] * y + T[r][2] * z + T[r][3];      // icp.py:116 on the float64 point
             }
@@ -369,7 +371,7 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
                   const int o = tidx[j];
                   double e = 0.0;
 #pragma unroll
-                  for (int r = 0; r < 3; ++r) { const double df = ad[r] - gtgt64[3 * o + r]; e += df * df; }
+                  for (int r = 0; r < 3; ++r) { const double df = ad[r] - gtgt64[3 * j + r]; e += df * df; }
                   if (e < bv || (e == bv && o < bo)) { bv = e; bo = o; bp = j; }
                 }
               }
@@ -409,8 +411,8 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
         if (i < n) {
           double x, y, z, pd[3], qd[3];
           if constexpr (F64) {                                // the float64 points themselves (original order)
-            const int so = sidx[i], to = tidx[sh_prev[i]];
-            x = gsrc64[3 * so]; y = gsrc64[3 * so + 1]; z = gsrc64[3 * so + 2];
+            const int to = sh_prev[i];
+            x = gsrc64[3 * i]; y = gsrc64[3 * i + 1]; z = gsrc64[3 * i + 2];
             qd[0] = gtgt64[3 * to]; qd[1] = gtgt64[3 * to + 1]; qd[2] = gtgt64[3 * to + 2];
           } else {
             const float4 v = src_lds ? sh_src[i] : ssrc[i];

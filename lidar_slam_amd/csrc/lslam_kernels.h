@@ -71,6 +71,9 @@ struct PruneScratch {                      // Morton-sorted copies: problem k ow
   float2* src_sorted; uint16_t* src_index;
   float2* tgt_sorted; uint16_t* tgt_index;
   int64_t src_stride, tgt_stride;          // = max_src_n, max_tgt_n of the batch
+  // float64-exact mode: the float64 clouds in the same sorted order (written by icp_sort_kernel), so that the moments read
+  // them sequentially / from neighbouring lines instead of gathering 16 bytes per point from the caller's order
+  double2* src64_sorted; double2* tgt64_sorted;
 };
 struct PruneLayout { uint32_t aabb_off, src_off, prev_off, red_off; unsigned* debug_counter; };
 bool icp_pruned_supported(int dim, int64_t max_src_n, int64_t max_tgt_n);
@@ -85,6 +88,7 @@ struct PruneScratch3 {
   float4* src_sorted; uint16_t* src_index;
   float4* tgt_sorted; uint16_t* tgt_index;
   int64_t src_stride, tgt_stride;
+  double* src64_sorted; double* tgt64_sorted;      // float64-exact mode: 3 doubles per point, sorted order
 };
 bool icp_pruned3_supported(int64_t max_src_n, int64_t max_tgt_n);
 hipError_t launch_icp_pruned3(IcpBatchArgs a, const PruneScratch3& sc, int S, int64_t max_src_n, int64_t max_tgt_n, hipStream_t stream);
