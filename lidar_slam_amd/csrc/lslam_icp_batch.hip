@@ -24,9 +24,11 @@
 // with |t|² kept beside the target in LDS.  g is only a filter: its float32 error against the exact
 // direct-difference distance is bounded by E = c·2⁻²⁴·R(R + |a|) (R = largest |t| of the problem), so the
 // exact winner lies in a chunk whose filter minimum is within τ = 2E + 9·2⁻²⁴·d² of the best one.  The sweep
-// keeps the three smallest chunk minima (two with their chunk id); chunks within τ are then re-evaluated
-// with the exact recipe.  If a third chunk is within τ (rare on random clouds; always on lattices or clouds
-// far from the origin) the wave falls back to the exact sweep — results are identical by construction.
+// keeps the three smallest chunk minima (two with their chunk id).  Every lane then re-evaluates the best chunk
+// of each of its points with the exact recipe; the few points with a second chunk within τ (≈ 1 % on C4), or a
+// third (≈ 10⁻⁴: then any target may be the winner), are searched one at a time by the whole wave (coop_exact).
+// Only when many points of a wave have a third chunk within τ (lattices, clouds far from the origin) does the
+// wave fall back to the exact sweep — results are identical by construction.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,6 +38,7 @@
 
 namespace lslam {
 
+constexpr int kTileAlign = kFilterChunk * 16;            // one filter chunk of the widest point (float4): see exact_chunk
 template <int DIM> struct TilePoint;
 template <> struct TilePoint<2> { using type = float2; static constexpr int kFloats = 2; };
 template <> struct TilePoint<3> { using type = float4; static constexpr int kFloats = 4; };
@@ -160,26 +163,82 @@ __device__ __forceinline__ void filter_sweep(const typename TilePoint<DIM>::type
 // exact distances of the targets of one filter chunk: minimum of the 64-bit key (distance bits, index) — distances
 // are non-negative floats, whose order is the order of their bit patterns, so one unsigned compare is the
 // lexicographic (distance, lowest index) rule
+// The low word of the key is the target's BYTE OFFSET in the tile (index × sizeof(point)): it orders like the index and is
+// what the address arithmetic produces anyway; exact_index() turns a finished key into the index.
+template <int DIM>
+__device__ __forceinline__ int exact_index(unsigned long long key) { return (int)((unsigned)key / (unsigned)sizeof(typename TilePoint<DIM>::type)); }
+
 template <int DIM, bool SEC>
 __device__ __forceinline__ void exact_chunk(const typename TilePoint<DIM>::type* tile, int chunk, int lane, const float (&a)[DIM],
                                             unsigned long long& best, float& bd, float& sec) {
   using TP = typename TilePoint<DIM>::type;
-  const int j0 = chunk * kFilterChunk;
-  // opaque copy of the lane id: otherwise the 32 rotated offsets are hoisted out of the ICP loop as 32 live
-  // registers (spilled, then reloaded from scratch at every use)
-  asm volatile("" : "+v"(lane));
-#pragma unroll 8
-  for (int kk = 0; kk < kFilterChunk; ++kk) {
-    const int j = j0 + ((kk + lane) & (kFilterChunk - 1));   // rotated start: every chunk begins on the same banks
+  constexpr unsigned kB = (unsigned)sizeof(TP);
+  // every chunk begins on the same LDS banks, so lane l starts at target (l mod 32) of its chunk and visits target
+  // (k XOR l) at step k: one v_xor per address (a rotation costs an add, an and and a shift-add), conflict-free like the rotation.
+  // Opaque: otherwise the 32 offsets are hoisted out of the ICP loop as 32 live registers (spilled, reloaded at every use)
+  unsigned r = (unsigned)lane & (unsigned)(kFilterChunk - 1);
+  asm volatile("" : "+v"(r));
+  // the arithmetic is done on the 32-bit LDS address itself (an address_space(3) pointer as an integer; through the generic
+  // pointer the compiler adds the tile base to every offset again).  The tile starts the dynamic LDS block, which is aligned
+  // to a chunk (kTileAlign), so the XOR stays inside the chunk.
+  typedef float __attribute__((ext_vector_type(TilePoint<DIM>::kFloats))) Vec;
+  typedef const __attribute__((address_space(3))) Vec* LdsPoint;
+  const unsigned tile0 = (unsigned)(size_t)(LdsPoint)(const void*)tile;
+  const unsigned first = tile0 + (unsigned)chunk * (kFilterChunk * kB) + r * kB;
+  unsigned long long k = ~0ull;                              // low word: the LDS address (orders like the index)
+  // eight targets per trip, their loads issued together: one LDS round trip per eight targets instead of one per target
+#pragma unroll 1
+  for (int h = 0; h < kFilterChunk; h += 8) {
+    unsigned at[8];
+    Vec v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      at[c] = first ^ ((unsigned)(h + c) * kB);
+      v[c] = *(LdsPoint)(size_t)at[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float d;
+      if constexpr (DIM == 2) d = dist2(a[0], a[1], v[c].x, v[c].y);
+      else d = dist2(a[0], a[1], a[2], v[c].x, v[c].y, v[c].z);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | at[c];
+      k = key < k ? key : k;
+      if constexpr (SEC) {                                   // float64-exact mode: smallest and second smallest distance seen (a near tie?)
+        sec = __builtin_amdgcn_fmed3f(bd, sec, d);
+        bd = fminf(bd, d);
+      }
+    }
+  }
+  best = k - tile0;                                          // 32 keys were compared: k is one of them
+}
+
+// ONE source point (wave-uniform coordinates) against the targets [j0, j0 + cnt) of the resident tile, the 64 lanes together:
+// for the rare points whose filter decision names a second chunk (cnt = kFilterChunk) or cannot be confined to two chunks
+// (cnt = the whole tile).  Handling those few points one by one costs the wave a few hundred instructions; evaluating the
+// second chunk for all 64 lanes because one of them asked, or re-running the whole sweep with the exact recipe because one
+// point of 512 had three close chunks, cost it 2 % and 7 % of the C4 kernel.  Every lane returns the same values.
+template <int DIM, bool SEC>
+__device__ __forceinline__ void coop_exact(const typename TilePoint<DIM>::type* tile, int j0, int cnt, const float (&a)[DIM], int lane,
+                                           unsigned long long& best, float& bd, float& sec) {
+  using TP = typename TilePoint<DIM>::type;
+  best = ~0ull; bd = INFINITY; sec = INFINITY;
+  for (int j = j0 + lane; j < j0 + cnt; j += kWave) {
     const TP v = tile[j];
     float d;
     if constexpr (DIM == 2) d = dist2(a[0], a[1], v.x, v.y);
     else d = dist2(a[0], a[1], a[2], v.x, v.y, v.z);
-    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | ((unsigned)j * (unsigned)sizeof(TP));
     best = key < best ? key : best;
-    if constexpr (SEC) {                                     // float64-exact mode: smallest and second smallest distance seen (a near tie?)
-      sec = __builtin_amdgcn_fmed3f(bd, sec, d);
-      bd = fminf(bd, d);
+    if constexpr (SEC) { sec = __builtin_amdgcn_fmed3f(bd, sec, d); bd = fminf(bd, d); }
+  }
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(best, o, kWave);
+    best = other < best ? other : best;
+    if constexpr (SEC) {                                     // two multisets: the second smallest of the union
+      const float b2 = __shfl_xor(bd, o, kWave), s2 = __shfl_xor(sec, o, kWave);
+      sec = fminf(fmaxf(bd, b2), fminf(sec, s2));
+      bd = fminf(bd, b2);
     }
   }
 }
@@ -188,7 +247,7 @@ template <int DIM, int P, int CHUNK, bool FILTER, bool F64>
 __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
   using TP = typename TilePoint<DIM>::type;
   constexpr int kAcc = AccLayout<DIM>::kTotal;
-  extern __shared__ __align__(16) unsigned char smem[];
+  extern __shared__ __align__(kTileAlign) unsigned char smem[];
   TP* tile = reinterpret_cast<TP*>(smem);
   float* wtile = reinterpret_cast<float*>(smem + args.tile_bytes);            // |t|² per target (planar FILTER build; 3-D keeps it in .w)
   float* sh_src = reinterpret_cast<float*>(smem + args.tile_bytes + args.w_bytes);   // the source cloud, DIM floats per point
@@ -393,16 +452,21 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
         for (int p = 0; p < P; ++p)
 #pragma unroll
           for (int r = 0; r < DIM; ++r) a[p][r] = -0.5f * na[p][r];
-        bool two[P], fall = false;
+        // two[p]: a second chunk can hold the winner; third[p]: more than two can (then any target may)
+        bool two[P], third[P];
+        int nthird = 0;                                        // wave-uniform
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          bool third;
-          filter_decide<DIM>(a[p], Rt, b1[p], b2[p], b3[p], nt, two[p], third);
-          fall |= (base + tid * P + p < n) && third;
+          filter_decide<DIM>(a[p], Rt, b1[p], b2[p], b3[p], nt, two[p], third[p]);
+          const bool owns = base + tid * P + p < n;
+          two[p] &= owns; third[p] &= owns;
+          nthird += __popcll(__ballot(third[p]));
         }
         f_tries++;
         if (args.debug && lane == 0) atomicAdd(args.debug, 1u);
-        if (__any(fall)) {
+        // a few such points are searched one by one by the whole wave (coop_exact: ≈ m/8 instructions each, against ≈ 5·m·P for
+        // the exact sweep); on lattices and on clouds far from the origin most points are: exact sweep
+        if (nthird > 8 * P) {
           f_fails++;
           if (args.debug && lane == 0) atomicAdd(args.debug + 1, 1u);
         } else {
@@ -411,19 +475,33 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
             unsigned long long k1 = ~0ull;
             float bd = INFINITY, sec = INFINITY;
             exact_chunk<DIM, F64>(tile, i1[p], lane, a[p], k1, bd, sec);
-            if (__any(two[p])) {
-              unsigned long long k2 = k1;
-              float bd2 = bd, sec2 = sec;
-              exact_chunk<DIM, F64>(tile, i2[p], lane, a[p], k2, bd2, sec2);
-              k1 = two[p] ? k2 : k1;
-              bd = two[p] ? bd2 : bd;
-              sec = two[p] ? sec2 : sec;
+            const unsigned long long m3 = __ballot(third[p]);
+            unsigned long long todo = __ballot(two[p]) | m3;
+            while (todo) {
+              const int l = __builtin_ctzll(todo);
+              todo &= todo - 1;
+              float au[DIM];
+#pragma unroll
+              for (int r = 0; r < DIM; ++r) au[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[p][r]), l));
+              const bool all = (m3 >> l) & 1ull;
+              const int c2 = __builtin_amdgcn_readlane(i2[p], l);
+              unsigned long long kc;
+              float bc, sc;
+              coop_exact<DIM, F64>(tile, all ? 0 : c2 * kFilterChunk, all ? m_padded : kFilterChunk, au, lane, kc, bc, sc);
+              if (lane == l) {
+                if (all) { k1 = kc; bd = bc; sec = sc; }       // the whole tile: supersedes the first chunk
+                else {
+                  k1 = kc < k1 ? kc : k1;
+                  sec = fminf(fmaxf(bd, bc), fminf(sec, sc));
+                  bd = fminf(bd, bc);
+                }
+              }
             }
-            bi[p] = (int)(unsigned)k1;
-            if constexpr (F64) {                               // every target within lim of the winner lies in these chunks (τ was widened)
+            bi[p] = exact_index<DIM>(k1);
+            if constexpr (F64) {                               // every target within lim of the winner lies in the chunks searched (τ was widened)
               const int i = base + tid * P + p;
               const float lim = near_lim(bd, nt);
-              refine_point(a[p], i, lim, (i < n && sec <= lim) ? (two[p] ? 2 : 1) : 0, i1[p], i2[p], kFilterChunk, bi[p]);
+              refine_point(a[p], i, lim, (i < n && sec <= lim) ? (third[p] ? 3 : (two[p] ? 2 : 1)) : 0, i1[p], i2[p], kFilterChunk, bi[p]);
             }
             const TP v = tile[bi[p]];
             q[p][0] = v.x; q[p][1] = v.y;
