@@ -144,14 +144,44 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2) {
   }
 }
 
+// One chunk of 16 sorted targets against ONE point of this lane, the chunk chosen by the lane (a gather): every target is
+// compared, (bd, sec) = the smallest and second smallest distance over everything evaluated for the point so far, at = the LDS
+// address of the nearest target.  Lane l visits target (k XOR l) at step k: chunks start on the same banks, and the XOR
+// costs one instruction per address (the arithmetic is done on the 32-bit LDS address: see lslam_icp_batch.hip, exact_chunk).
+constexpr int kPruneTileAlign = kPruneChunk * 8;
+__device__ __forceinline__ void prune_eval_chunk(unsigned tile0, int chunk, int lane, float x, float y, float& bd, float& sec, unsigned& at) {
+  typedef float __attribute__((ext_vector_type(2))) Vec;
+  typedef const __attribute__((address_space(3))) Vec* LdsPoint;
+  unsigned r = (unsigned)lane & (unsigned)(kPruneChunk - 1);
+  asm volatile("" : "+v"(r));                                  // opaque: keeps the 16 offsets from being hoisted out of the ICP loop (and spilled)
+  const unsigned first = tile0 + (unsigned)chunk * (kPruneChunk * 8u) + r * 8u;
+#pragma unroll 1
+  for (int h = 0; h < kPruneChunk; h += 8) {
+    unsigned a8[8];
+    Vec v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { a8[c] = first ^ ((unsigned)(h + c) * 8u); v[c] = *(LdsPoint)(size_t)a8[c]; }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float d = dist2(x, y, v[c].x, v[c].y);
+      const bool lt = d < bd;
+      sec = __builtin_amdgcn_fmed3f(bd, sec, d);
+      at = lt ? a8[c] : at;
+      bd = lt ? d : bd;
+    }
+  }
+}
+
 // F64: the float64-exact mode (lslam_device.h: NearTie; args.src64 / args.tgt64 set) — pruning and tie detection use the
 // near-tie window lim(D) instead of D, near ties are decided on the float64 points, the moments are taken from them.
-template <int P, bool F64>
+// LIST: every lane evaluates the chunks ITS points need, one (point, chunk) at a time with gathered reads, instead of the
+// whole wave evaluating every chunk any of its points needs (see the sweep below).
+template <int P, bool F64, bool LIST>
 __global__ void __launch_bounds__(kIcpBatchMaxThreads, 8)      // ≤ 64 VGPRs: two 16-wave workgroups per CU (measured 1.3× faster than 119 VGPRs / one workgroup)
 icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   constexpr int CHUNK = kPruneChunk;
   constexpr int kAcc = AccLayout<2>::kTotal;
-  extern __shared__ __align__(16) unsigned char smem[];
+  extern __shared__ __align__(kPruneTileAlign) unsigned char smem[];
   float2* tile = reinterpret_cast<float2*>(smem);                                   // sorted targets, padded
   float4* aabb = reinterpret_cast<float4*>(smem + lay.aabb_off);                    // per chunk {x0,y0,x1,y1}
   float2* sh_src = reinterpret_cast<float2*>(smem + lay.src_off);                   // sorted sources: read twice per iteration, so they live on chip
@@ -179,6 +209,7 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   const double2* __restrict__ gtgt64 = F64 ? sc.tgt64_sorted + ts : nullptr;
   if (tid < 16) sh_T[tid] = args.init_T[(int64_t)16 * pair + tid];
   if (F64 && tid == 0) { sh_flag[1] = 0; sh_flag[2] = 0; }   // bits of max |t|², max |p|²
+  if (tid == 0) sh_flag[3] = 0;                              // the next slab of 64·P sources to be searched (phase A)
   float tmax = 0.f, smax = 0.f;
   for (int j = tid; j < nchunks * CHUNK; j += blockDim.x) {
     const float2 v = (j < m) ? sc.tgt_sorted[ts + j] : make_float2(kFar, kFar);
@@ -214,6 +245,12 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
   if (tid == 0) { StopState st0; stop_init(st0); *sh_stop = st0; *sh_err = 0.0; }       // read first after the barrier that precedes the solve
   const int per_pass = blockDim.x * P;
   const int passes = n > 0 ? (n + per_pass - 1) / per_pass : 1;
+#ifdef LSLAM_PRUNE_PROFILE
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime();
+#define PRUNE_MARK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); prof[k] += now_ - pt; pt = now_; } while (0)
+#else
+#define PRUNE_MARK(k) do {} while (0)
+#endif
 
   for (;;) {
     double T[2][4];
@@ -228,9 +265,21 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
     auto reach = [&](float b) { return F64 ? __builtin_fmaf(b, nt.K1, nt.C) : b; };
 
     // ---- phase A: nearest neighbours (float32); the matches go to LDS (they also seed the next iteration)
-    for (int pass = 0; pass < passes; ++pass) {
-      const int base = pass * per_pass;
-      if (base + (tid & ~63) * P >= n) continue;           // this wave owns no source in this pass
+    // With more slabs of 64·P consecutive sorted sources than waves, the waves take them from a counter: the search time of a
+    // slab depends on where it lies (how many chunks its points still need), and with a fixed slab-to-wave map the workgroup
+    // waited at the barrier for its slowest wave (C4: 22.8 -> 22.4 ms).  The matches go to LDS by source position, so who
+    // searched a slab does not matter — but phase B then needs a barrier, which costs LiDAR-sized problems (one slab per
+    // wave, nothing to balance) 10 %: they keep the fixed map.
+    const int nslabs = (n + kWave * P - 1) / (kWave * P);
+    const bool take = nslabs > nwaves;
+    for (int round = 0;; ++round) {
+      int slab = wave + nwaves * round;
+      if (take) {
+        if (lane == 0) slab = atomicAdd(&sh_flag[3], 1);
+        slab = __builtin_amdgcn_readfirstlane(slab);
+      }
+      if (slab >= nslabs) break;
+      const int base = (slab - wave) * kWave * P;            // base + tid·P + p = slab·64·P + lane·P + p
       float ax[P], ay[P];
       float wx0 = INFINITY, wy0 = INFINITY, wx1 = -INFINITY, wy1 = -INFINITY;
 #pragma unroll
@@ -245,123 +294,205 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
         }
       }
       wx0 = wave_min_f(wx0); wy0 = wave_min_f(wy0); wx1 = wave_max_f(wx1); wy1 = wave_max_f(wy1);
+      PRUNE_MARK(0);
 
-      // ---- start from last iteration's match: a tight bound before the first chunk ------------
-      float best[P], second[P];                            // smallest and second smallest chunk minimum seen so far
-      int bchunk[P];
       bool tie = false;
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int i = base + tid * P + p;
-        best[p] = (i < n) ? INFINITY : -INFINITY;          // lanes without a point never ask for a chunk
-        second[p] = INFINITY;
-        bchunk[p] = 0;
-        if (i < n) {
-          const int pv = sh_prev[i];
-          if (pv != 0xffff) {
-            const float2 q = tile[pv];
-            // a bound, not yet a candidate: its chunk will beat it strictly (float64-exact mode: by more than the near-tie window,
-            // so that the bound itself is never mistaken for a second candidate)
-            const float ds = dist2(ax[p], ay[p], q.x, q.y);
-            best[p] = F64 ? next_up(reach(ds) * 1.000001f) : next_up(ds);
-            bchunk[p] = pv / CHUNK;
-          } else {
-            // first iteration: both clouds are sorted along the same curve, so the target at the same
-            // relative rank is usually close — any evaluated point is a valid upper bound
-            const int g = (int)(((long long)i * m) / n);
-            const float2 q = tile[g];
-            const float ds = dist2(ax[p], ay[p], q.x, q.y);
-            best[p] = F64 ? next_up(reach(ds) * 1.000001f) : next_up(ds);
-            bchunk[p] = g / CHUNK;
-          }
-        }
-      }
-
-      // ---- sweep: 64 chunk boxes are tested at once, one per lane, against the wave's box and the wave's largest
-      // bound; the chunks that survive (a 64-bit ballot, walked with scalar bit operations) get a second look with
-      // every lane's OWN points and CURRENT bounds before they are evaluated.  (One box test per chunk with a
-      // compare → scalar branch each, two levels deep, spent a quarter of the kernel's instructions.)
-      const float4* t4 = reinterpret_cast<const float4*>(tile);
-      float wb = -INFINITY;
-#pragma unroll
-      for (int p = 0; p < P; ++p) wb = fmaxf(wb, best[p]);
-      wb = wave_max_f(wb);                                   // no lane can ask for a chunk farther than this from the wave's box
-      for (int c0 = 0; c0 < nchunks; c0 += 64) {
-        bool cand = false;
-        if (c0 + lane < nchunks) {
-          const float4 b = aabb[c0 + lane];
-          const float dx = fmaxf(fmaxf(b.x - wx1, wx0 - b.z), 0.f);
-          const float dy = fmaxf(fmaxf(b.y - wy1, wy0 - b.w), 0.f);
-          cand = reach(wb) >= __builtin_fmaf(dy, dy, dx * dx) * kPruneSafety;
-        }
-        unsigned long long todo = __ballot(cand);
-        while (todo) {
-          const int c = c0 + __builtin_ctzll(todo);
-          todo &= todo - 1;
-          const float4 b = aabb[c];
-          // the sorted sources of a wave sit on a Morton curve that sometimes jumps across the cloud; the wave's
-          // box is then large, each point's reach is not
-          bool need_own = false;
-#pragma unroll
-          for (int p = 0; p < P; ++p) {
-            const float ox = fmaxf(fmaxf(b.x - ax[p], ax[p] - b.z), 0.f);
-            const float oy = fmaxf(fmaxf(b.y - ay[p], ay[p] - b.w), 0.f);
-            need_own |= reach(best[p]) >= __builtin_fmaf(oy, oy, ox * ox) * kPruneSafety;
-          }
-          if (!__any(need_own)) continue;                    // nothing in this chunk can beat or tie any lane
-          float4 v[CHUNK / 2];
-#pragma unroll
-          for (int k = 0; k < CHUNK / 2; ++k) v[k] = t4[c * (CHUNK / 2) + k];
-#pragma unroll
-          for (int p = 0; p < P; ++p) {
-            float mn = dist2(ax[p], ay[p], v[0].x, v[0].y);
-            mn = fminf(mn, dist2(ax[p], ay[p], v[0].z, v[0].w));
-#pragma unroll
-            for (int k = 1; k < CHUNK / 2; ++k) {
-              const float d0 = dist2(ax[p], ay[p], v[k].x, v[k].y);
-              const float d1 = dist2(ax[p], ay[p], v[k].z, v[k].w);
-              mn = fminf(fminf(d0, d1), mn);
-            }
-            // equal minima of two chunks are found through the VALUES (second smallest == smallest) after the sweep:
-            // no per-chunk compare into a scalar mask
-            const bool lt = mn < best[p];
-            second[p] = __builtin_amdgcn_fmed3f(best[p], second[p], mn);
-            bchunk[p] = lt ? c : bchunk[p];
-            best[p] = lt ? mn : best[p];
-          }
-        }
-      }
-
       bool near[P];                                          // float64-exact mode: another target within the near-tie window of the winner
+      int pos[P];                                            // sorted position of the nearest target
+      float bd[P];                                           // its distance
+      if constexpr (LIST) {
+        typedef const __attribute__((address_space(3))) float2* LdsTile;
+        const unsigned tile0 = (unsigned)(size_t)(LdsTile)(const void*)tile;
+        // ---- seed: the chunk of last iteration's match (first iteration: of the target at the same relative rank — both clouds
+        // are sorted along the same curve), compared target by target by the lane itself: an exact bound before any box test
+        float sec[P];                                        // second smallest distance over everything evaluated for the point
+        unsigned at[P];                                      // LDS address of the nearest target so far
+        int own[P];
 #pragma unroll
-      for (int p = 0; p < P; ++p) {
-        if constexpr (F64) near[p] = (second[p] <= near_lim(best[p], nt)) && (best[p] < INFINITY);
-        else { near[p] = false; tie |= (second[p] == best[p]) && (best[p] < INFINITY); }
-      }
-      // ---- fix-up inside the winning chunk: position of the minimum; equal distances are left to the pass below ----
-      int pos[P];
-      float bd[P];
-      int rot = lane;
-      asm volatile("" : "+v"(rot));                          // opaque: keeps the 16 rotated offsets from being hoisted out of the ICP loop (and spilled)
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int j0 = bchunk[p] * CHUNK;
-        float sec2 = INFINITY;                               // second smallest distance of the chunk: equal to the smallest ⇔ two equally near targets
-        bd[p] = INFINITY; pos[p] = j0;
-#pragma unroll
-        for (int kk = 0; kk < CHUNK; ++kk) {
-          const int k = (kk + rot) & (CHUNK - 1);
-          const float2 q = tile[j0 + k];
-          const float d = dist2(ax[p], ay[p], q.x, q.y);
-          // all in vector registers: a per-element compare into a scalar mask (v_cmp → s_and → s_or chains) was measured
-          // 1.5× slower for the whole kernel
-          const bool lt = d < bd[p];
-          sec2 = __builtin_amdgcn_fmed3f(bd[p], sec2, d);
-          pos[p] = lt ? j0 + k : pos[p];
-          bd[p] = lt ? d : bd[p];
+        for (int p = 0; p < P; ++p) {
+          const int i = base + tid * P + p;
+          bd[p] = (i < n) ? INFINITY : -INFINITY;            // lanes without a point never ask for a chunk
+          sec[p] = INFINITY; at[p] = tile0; own[p] = -1;
+          if (i < n) {
+            const int pv = sh_prev[i];
+            own[p] = (pv != 0xffff ? pv : (int)(((long long)i * m) / n)) / CHUNK;
+            prune_eval_chunk(tile0, own[p], lane, ax[p], ay[p], bd[p], sec[p], at[p]);
+          }
         }
-        if constexpr (F64) { near[p] = (near[p] || (sec2 <= near_lim(bd[p], nt) && bd[p] < INFINITY)) && (base + tid * P + p < n); tie |= near[p]; }
-        else tie |= (sec2 == bd[p]) && (bd[p] < INFINITY);
+        float wb = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < P; ++p) wb = fmaxf(wb, bd[p]);
+        wb = wave_max_f(wb);                                 // no lane can ask for a chunk farther than this from the wave's box
+        PRUNE_MARK(1);
+        // ---- sweep: 64 chunk boxes are tested at once, one per lane, against the wave's box and the wave's largest bound.
+        // The survivors (a 64-bit ballot, walked with scalar bit operations) are tested against every point of every lane with
+        // its CURRENT bound; what a point still needs goes into a 64-bit list per point, and each lane then works through the
+        // lists of its points.  (Evaluating a surviving chunk for all 64·P points of the wave because one of them needed it
+        // was 58 % of the kernel's instructions.)
+        for (int c0 = 0; c0 < nchunks; c0 += 64) {
+          bool cand = false;
+          if (c0 + lane < nchunks) {
+            const float4 b = aabb[c0 + lane];
+            const float dx = fmaxf(fmaxf(b.x - wx1, wx0 - b.z), 0.f);
+            const float dy = fmaxf(fmaxf(b.y - wy1, wy0 - b.w), 0.f);
+            cand = reach(wb) >= __builtin_fmaf(dy, dy, dx * dx) * kPruneSafety;
+          }
+          unsigned long long todo = __ballot(cand);
+          if (!todo) continue;
+          unsigned long long list[P];
+#pragma unroll
+          for (int p = 0; p < P; ++p) list[p] = 0ull;
+          while (todo) {
+            const int t = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            // from the register of the lane that tested it (v_readlane), not from LDS again: a read per survivor, each waited
+            // for in turn, was a fifth of the kernel's wave time
+            const float4 b = aabb[c0 + t];                     // (v_readlane from the lane that tested the box was measured: 10 % slower)
+            const unsigned long long bit = 1ull << t;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              const float ox = fmaxf(fmaxf(b.x - ax[p], ax[p] - b.z), 0.f);
+              const float oy = fmaxf(fmaxf(b.y - ay[p], ay[p] - b.w), 0.f);
+              // the seed chunk was compared already: a second visit would read as a tie of the point with itself
+              const bool need = reach(bd[p]) >= __builtin_fmaf(oy, oy, ox * ox) * kPruneSafety && own[p] != c0 + t;
+              list[p] |= need ? bit : 0ull;
+            }
+          }
+          PRUNE_MARK(2);
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            unsigned long long mk = list[p];
+            while (__any(mk != 0ull)) {
+              if (mk != 0ull) {
+                const int t = __builtin_ctzll(mk);
+                mk &= mk - 1;
+                prune_eval_chunk(tile0, c0 + t, lane, ax[p], ay[p], bd[p], sec[p], at[p]);
+              }
+            }
+          }
+          PRUNE_MARK(3);
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const bool owns = base + tid * P + p < n;
+          pos[p] = (int)((at[p] - tile0) >> 3);
+          if constexpr (F64) { near[p] = owns && bd[p] < INFINITY && sec[p] <= near_lim(bd[p], nt); tie |= near[p]; }
+          else { near[p] = false; tie |= owns && bd[p] < INFINITY && sec[p] == bd[p]; }
+        }
+      } else {
+        // ---- start from last iteration's match: a tight bound before the first chunk ------------
+        float best[P], second[P];                            // smallest and second smallest chunk minimum seen so far
+        int bchunk[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int i = base + tid * P + p;
+          best[p] = (i < n) ? INFINITY : -INFINITY;          // lanes without a point never ask for a chunk
+          second[p] = INFINITY;
+          bchunk[p] = 0;
+          if (i < n) {
+            const int pv = sh_prev[i];
+            if (pv != 0xffff) {
+              const float2 q = tile[pv];
+              // a bound, not yet a candidate: its chunk will beat it strictly (float64-exact mode: by more than the near-tie window,
+              // so that the bound itself is never mistaken for a second candidate)
+              const float ds = dist2(ax[p], ay[p], q.x, q.y);
+              best[p] = F64 ? next_up(reach(ds) * 1.000001f) : next_up(ds);
+              bchunk[p] = pv / CHUNK;
+            } else {
+              // first iteration: both clouds are sorted along the same curve, so the target at the same
+              // relative rank is usually close — any evaluated point is a valid upper bound
+              const int g = (int)(((long long)i * m) / n);
+              const float2 q = tile[g];
+              const float ds = dist2(ax[p], ay[p], q.x, q.y);
+              best[p] = F64 ? next_up(reach(ds) * 1.000001f) : next_up(ds);
+              bchunk[p] = g / CHUNK;
+            }
+          }
+        }
+
+        // ---- sweep: 64 chunk boxes are tested at once, one per lane, against the wave's box and the wave's largest
+        // bound; the chunks that survive (a 64-bit ballot, walked with scalar bit operations) get a second look with
+        // every lane's OWN points and CURRENT bounds before they are evaluated.  (One box test per chunk with a
+        // compare → scalar branch each, two levels deep, spent a quarter of the kernel's instructions.)
+        const float4* t4 = reinterpret_cast<const float4*>(tile);
+        float wb = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < P; ++p) wb = fmaxf(wb, best[p]);
+        wb = wave_max_f(wb);                                   // no lane can ask for a chunk farther than this from the wave's box
+        for (int c0 = 0; c0 < nchunks; c0 += 64) {
+          bool cand = false;
+          if (c0 + lane < nchunks) {
+            const float4 b = aabb[c0 + lane];
+            const float dx = fmaxf(fmaxf(b.x - wx1, wx0 - b.z), 0.f);
+            const float dy = fmaxf(fmaxf(b.y - wy1, wy0 - b.w), 0.f);
+            cand = reach(wb) >= __builtin_fmaf(dy, dy, dx * dx) * kPruneSafety;
+          }
+          unsigned long long todo = __ballot(cand);
+          while (todo) {
+            const int c = c0 + __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float4 b = aabb[c];
+            // the sorted sources of a wave sit on a Morton curve that sometimes jumps across the cloud; the wave's
+            // box is then large, each point's reach is not
+            bool need_own = false;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              const float ox = fmaxf(fmaxf(b.x - ax[p], ax[p] - b.z), 0.f);
+              const float oy = fmaxf(fmaxf(b.y - ay[p], ay[p] - b.w), 0.f);
+              need_own |= reach(best[p]) >= __builtin_fmaf(oy, oy, ox * ox) * kPruneSafety;
+            }
+            if (!__any(need_own)) continue;                    // nothing in this chunk can beat or tie any lane
+            float4 v[CHUNK / 2];
+#pragma unroll
+            for (int k = 0; k < CHUNK / 2; ++k) v[k] = t4[c * (CHUNK / 2) + k];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              float mn = dist2(ax[p], ay[p], v[0].x, v[0].y);
+              mn = fminf(mn, dist2(ax[p], ay[p], v[0].z, v[0].w));
+#pragma unroll
+              for (int k = 1; k < CHUNK / 2; ++k) {
+                const float d0 = dist2(ax[p], ay[p], v[k].x, v[k].y);
+                const float d1 = dist2(ax[p], ay[p], v[k].z, v[k].w);
+                mn = fminf(fminf(d0, d1), mn);
+              }
+              // equal minima of two chunks are found through the VALUES (second smallest == smallest) after the sweep:
+              // no per-chunk compare into a scalar mask
+              const bool lt = mn < best[p];
+              second[p] = __builtin_amdgcn_fmed3f(best[p], second[p], mn);
+              bchunk[p] = lt ? c : bchunk[p];
+              best[p] = lt ? mn : best[p];
+            }
+          }
+        }
+
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if constexpr (F64) near[p] = (second[p] <= near_lim(best[p], nt)) && (best[p] < INFINITY);
+          else { near[p] = false; tie |= (second[p] == best[p]) && (best[p] < INFINITY); }
+        }
+        // ---- fix-up inside the winning chunk: position of the minimum; equal distances are left to the pass below ----
+        int rot = lane;
+        asm volatile("" : "+v"(rot));                          // opaque: keeps the 16 rotated offsets from being hoisted out of the ICP loop (and spilled)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int j0 = bchunk[p] * CHUNK;
+          float sec2 = INFINITY;                               // second smallest distance of the chunk: equal to the smallest ⇔ two equally near targets
+          bd[p] = INFINITY; pos[p] = j0;
+#pragma unroll
+          for (int kk = 0; kk < CHUNK; ++kk) {
+            const int k = (kk + rot) & (CHUNK - 1);
+            const float2 q = tile[j0 + k];
+            const float d = dist2(ax[p], ay[p], q.x, q.y);
+            // all in vector registers: a per-element compare into a scalar mask (v_cmp → s_and → s_or chains) was measured
+            // 1.5× slower for the whole kernel
+            const bool lt = d < bd[p];
+            sec2 = __builtin_amdgcn_fmed3f(bd[p], sec2, d);
+            pos[p] = lt ? j0 + k : pos[p];
+            bd[p] = lt ? d : bd[p];
+          }
+          if constexpr (F64) { near[p] = (near[p] || (sec2 <= near_lim(bd[p], nt) && bd[p] < INFINITY)) && (base + tid * P + p < n); tie |= near[p]; }
+          else tie |= (sec2 == bd[p]) && (bd[p] < INFINITY);
+        }
       }
       // ---- equal minima (duplicate or equidistant points, in one chunk or in two): exhaustive pass, lowest ORIGINAL index wins --
       if constexpr (F64) {
@@ -424,7 +555,10 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
         const int i = base + tid * P + p;
         if (i < n) sh_prev[i] = (uint16_t)pos[p];
       }
+      PRUNE_MARK(4);
     }
+    if (take) __syncthreads();                               // phase B reads matches that other waves wrote
+    PRUNE_MARK(5);
 
     // ---- phase B: float64 moments of the matched pairs (kept apart from the sweep: the 28 accumulator
     // registers are not live while the search runs) ------------------------------------------------
@@ -455,6 +589,7 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
       }
     }
 
+    PRUNE_MARK(6);
     acc.wave_reduce(box);
     if (lane == 0) acc.store(sh_red + (size_t)wave * kAcc);
     __syncthreads();
@@ -497,13 +632,20 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
       if (lane < 16) sh_T[lane] = tn;
       if (lane == 0) {
         sh_flag[0] = stop ? 1 : 0;
+        sh_flag[3] = 0;                                      // every wave is past its last slab (the barrier above)
         *sh_stop = st;
         *sh_err = err;
       }
     }
     __syncthreads();
+    PRUNE_MARK(7);
     if (sh_flag[0]) break;
   }
+#ifdef LSLAM_PRUNE_PROFILE
+  // cycles per phase, summed over the waves of the launch: [2 + k] of the debug block (printed by the launcher under LSLAM_DEBUG)
+  if (lay.debug_counter && lane == 0)
+    for (int k = 0; k < 8; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(lay.debug_counter) + 1 + k, prof[k]);
+#endif
 
   if (tid < 16) args.out_T[(int64_t)16 * pair + tid] = sh_T[tid];
   if (tid == 0) {
@@ -555,9 +697,18 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
     }
     static unsigned* dbg = nullptr;
     if (getenv("LSLAM_DEBUG")) {
-      if (!dbg) { (void)hipMalloc(&dbg, 4); }
-      else { unsigned h = 0; (void)hipMemcpy(&h, dbg, 4, hipMemcpyDeviceToHost); fprintf(stderr, "[lslam] exhaustive tie passes of the previous launch: %u\n", h); }
-      (void)hipMemset(dbg, 0, 4);
+      if (!dbg) { (void)hipMalloc(&dbg, 80); }
+      else {
+        unsigned long long h[10];
+        (void)hipMemcpy(h, dbg, 80, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[lslam] exhaustive tie passes of the previous launch: %u\n", (unsigned)h[0]);
+#ifdef LSLAM_PRUNE_PROFILE
+        double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)h[1 + k];
+        fprintf(stderr, "[lslam] pruned kernel, share of wave cycles: transform+box %.3f  seed %.3f  box tests %.3f  lists %.3f  ties+store %.3f  (pass loop) %.3f  moments %.3f  reduce+solve+barriers %.3f\n",
+                h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot, h[7] / tot, h[8] / tot);
+#endif
+      }
+      (void)hipMemset(dbg, 0, 80);
       lay.debug_counter = dbg;
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, smem);
@@ -567,14 +718,29 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
     return hipGetLastError();
   };
   if ((a.src64 == nullptr) != (a.tgt64 == nullptr)) return hipErrorInvalidValue;
-  if (a.src64) {
-    if (P == 1) return launch(icp_pruned_kernel<1, true>);
-    if (P == 2) return launch(icp_pruned_kernel<2, true>);
-    return launch(icp_pruned_kernel<4, true>);
+  // per-lane lists (LIST) against whole-wave chunk evaluation, same box: C4 22.4 vs 24.1 ms, float64-exact 23.9 vs 27.5 ms;
+  // the LiDAR-sized C3 batch 2.23 vs 2.55 ms in float64-exact mode but 1.98 vs 1.91 ms in float32 (few chunks, short lists:
+  // the gathered reads' latency is not hidden)
+  bool list = a.src64 != nullptr || max_src_n >= 2048;
+  if (const char* env = getenv("LSLAM_ICP_PRUNE_LIST")) list = atoi(env) != 0;
+  if (list) {
+    if (a.src64) {
+      if (P == 1) return launch(icp_pruned_kernel<1, true, true>);
+      if (P == 2) return launch(icp_pruned_kernel<2, true, true>);
+      return launch(icp_pruned_kernel<4, true, true>);
+    }
+    if (P == 1) return launch(icp_pruned_kernel<1, false, true>);
+    if (P == 2) return launch(icp_pruned_kernel<2, false, true>);
+    return launch(icp_pruned_kernel<4, false, true>);
   }
-  if (P == 1) return launch(icp_pruned_kernel<1, false>);
-  if (P == 2) return launch(icp_pruned_kernel<2, false>);
-  return launch(icp_pruned_kernel<4, false>);
+  if (a.src64) {
+    if (P == 1) return launch(icp_pruned_kernel<1, true, false>);
+    if (P == 2) return launch(icp_pruned_kernel<2, true, false>);
+    return launch(icp_pruned_kernel<4, true, false>);
+  }
+  if (P == 1) return launch(icp_pruned_kernel<1, false, false>);
+  if (P == 2) return launch(icp_pruned_kernel<2, false, false>);
+  return launch(icp_pruned_kernel<4, false, false>);
 }
 
 }  // namespace lslam
