@@ -68,9 +68,17 @@ __device__ inline void bitonic_sort(unsigned* keys, int len) {
   __syncthreads();
 }
 
-// One workgroup per problem: Morton-sorted copies of target and source + their original indices.
+// One workgroup per problem: copies of target and source in an order that keeps neighbours together + their original indices.
+//
+// That order is the Morton order of a grid over the target's box — unless the cloud ARRIVES in a compact order.  A LiDAR scan
+// does: consecutive beams hit neighbouring points of the same wall, so 16 consecutive points already form a small box (the
+// boxes of a scan add up to about the length of the walls, whatever the number of beams; Morton-sorted points of a filled
+// area add up to √(n·W·H)/2).  keep bit 0 / 1: the target / the source stays as it is when the half perimeters of its
+// chunk boxes sum to no more than that figure (+ 2(W+H) for clouds on a line).  On the C3 sequence this takes the batch from
+// 1.94 to 1.29 ms: the two bitonic sorts were a quarter of it, and the search itself is faster on beam order.  The search
+// is exact for any order; the order only decides how much is pruned.
 __global__ void __launch_bounds__(kSortThreads)
-icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2) {
+icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned* keys = reinterpret_cast<unsigned*>(smem);
   __shared__ float sbox[4];
@@ -85,23 +93,54 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2) {
   // start anywhere in a larger packed buffer, the scratch is sized for this batch only
   const int64_t ss = (int64_t)pair * sc.src_stride, ts = (int64_t)pair * sc.tgt_stride;
 
-  // bounding box of the target
-  float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
-  for (int j = tid; j < m; j += kSortThreads) {
-    const float2 q = tgt[j];
-    x0 = fminf(x0, q.x); y0 = fminf(y0, q.y); x1 = fmaxf(x1, q.x); y1 = fmaxf(y1, q.y);
-  }
-  x0 = wave_min_f(x0); y0 = wave_min_f(y0); x1 = wave_max_f(x1); y1 = wave_max_f(y1);
-  if ((tid & 63) == 0) { red[tid >> 6][0] = x0; red[tid >> 6][1] = y0; red[tid >> 6][2] = x1; red[tid >> 6][3] = y1; }
-  __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < kSortThreads / 64; ++w) {
-      x0 = fminf(x0, red[w][0]); y0 = fminf(y0, red[w][1]); x1 = fmaxf(x1, red[w][2]); y1 = fmaxf(y1, red[w][3]);
+  // bounding box of a cloud, the same four numbers in every thread
+  auto cloud_box = [&](const float2* pts, int cnt, float& x0, float& y0, float& x1, float& y1) {
+    x0 = INFINITY; y0 = INFINITY; x1 = -INFINITY; y1 = -INFINITY;
+    for (int j = tid; j < cnt; j += kSortThreads) {
+      const float2 q = pts[j];
+      x0 = fminf(x0, q.x); y0 = fminf(y0, q.y); x1 = fmaxf(x1, q.x); y1 = fmaxf(y1, q.y);
     }
-    sbox[0] = x0; sbox[1] = y0; sbox[2] = x1; sbox[3] = y1;
-  }
-  __syncthreads();
-  x0 = sbox[0]; y0 = sbox[1]; x1 = sbox[2]; y1 = sbox[3];
+    x0 = wave_min_f(x0); y0 = wave_min_f(y0); x1 = wave_max_f(x1); y1 = wave_max_f(y1);
+    __syncthreads();                                         // red / sbox of an earlier call are consumed
+    if ((tid & 63) == 0) { red[tid >> 6][0] = x0; red[tid >> 6][1] = y0; red[tid >> 6][2] = x1; red[tid >> 6][3] = y1; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < kSortThreads / 64; ++w) {
+        x0 = fminf(x0, red[w][0]); y0 = fminf(y0, red[w][1]); x1 = fmaxf(x1, red[w][2]); y1 = fmaxf(y1, red[w][3]);
+      }
+      sbox[0] = x0; sbox[1] = y0; sbox[2] = x1; sbox[3] = y1;
+    }
+    __syncthreads();
+    x0 = sbox[0]; y0 = sbox[1]; x1 = sbox[2]; y1 = sbox[3];
+  };
+  // does the cloud arrive in a compact order?  (fixed reduction order: the same answer in every run)
+  auto compact_as_given = [&](const float2* pts, int cnt, float w, float h) -> bool {
+    float sum = 0.f;
+    for (int c = tid; c * kPruneChunk < cnt; c += kSortThreads) {
+      float cx0 = INFINITY, cy0 = INFINITY, cx1 = -INFINITY, cy1 = -INFINITY;
+      for (int k = 0; k < kPruneChunk && c * kPruneChunk + k < cnt; ++k) {
+        const float2 q = pts[c * kPruneChunk + k];
+        cx0 = fminf(cx0, q.x); cy0 = fminf(cy0, q.y); cx1 = fmaxf(cx1, q.x); cy1 = fmaxf(cy1, q.y);
+      }
+      sum += (cx1 - cx0) + (cy1 - cy0);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6][0] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      float tot = 0.f;
+      for (int wv = 0; wv < kSortThreads / 64; ++wv) tot += red[wv][0];
+      sbox[0] = (tot <= 0.5f * sqrtf((float)cnt * w * h) + 2.f * (w + h)) ? 1.f : 0.f;      // NaN / inf extents: false, the cloud is sorted
+    }
+    __syncthreads();
+    return sbox[0] != 0.f;
+  };
+
+  float x0, y0, x1, y1;
+  cloud_box(tgt, m, x0, y0, x1, y1);
+  const bool keep_tgt = keep_forced >= 0 ? (keep_forced & 1) != 0 : compact_as_given(tgt, m, x1 - x0, y1 - y0);
   const int G = m >= 2048 ? 32 : (m >= 512 ? 16 : 8);
   const float sx = (x1 > x0) ? (float)G / (x1 - x0) : 0.f, sy = (y1 > y0) ? (float)G / (y1 - y0) : 0.f;
   auto cell_of = [&](float x, float y) -> unsigned {
@@ -111,31 +150,38 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2) {
   };
 
   // ---- target ----
+  __syncthreads();
   for (int j = tid; j < len_pow2; j += kSortThreads) {
     unsigned k = 0xffffffffu;
-    if (j < m) { const float2 q = tgt[j]; k = (cell_of(q.x, q.y) << 13) | (unsigned)j; }
+    if (j < m) { const float2 q = tgt[j]; k = (keep_tgt ? 0u : (cell_of(q.x, q.y) << 13)) | (unsigned)j; }
     keys[j] = k;
   }
-  bitonic_sort(keys, len_pow2);
+  if (!keep_tgt) bitonic_sort(keys, len_pow2); else __syncthreads();
   for (int j = tid; j < m; j += kSortThreads) {
     const unsigned o = keys[j] & 8191u;
     sc.tgt_sorted[ts + j] = tgt[o];
     sc.tgt_index[ts + j] = (uint16_t)o;
     if (a.tgt64) sc.tgt64_sorted[ts + j] = reinterpret_cast<const double2*>(a.tgt64)[t0 + o];
   }
+  // ---- source: as given if compact (a rigid motion does not undo that), else placed by its initial transform into the target's grid ----
+  bool keep_src = keep_forced >= 0 ? (keep_forced & 2) != 0 : false;
+  if (keep_forced < 0) {
+    float u0, v0, u1, v1;
+    cloud_box(src, n, u0, v0, u1, v1);
+    keep_src = compact_as_given(src, n, u1 - u0, v1 - v0);
+  }
   __syncthreads();
-  // ---- source, placed by its initial transform into the target's grid ----
   const double* T = a.init_T + (int64_t)16 * pair;
   const float t00 = (float)T[0], t01 = (float)T[1], t03 = (float)T[3], t10 = (float)T[4], t11 = (float)T[5], t13 = (float)T[7];
   for (int i = tid; i < len_pow2; i += kSortThreads) {
     unsigned k = 0xffffffffu;
     if (i < n) {
       const float2 p = src[i];
-      k = (cell_of(t00 * p.x + t01 * p.y + t03, t10 * p.x + t11 * p.y + t13) << 13) | (unsigned)i;
+      k = (keep_src ? 0u : (cell_of(t00 * p.x + t01 * p.y + t03, t10 * p.x + t11 * p.y + t13) << 13)) | (unsigned)i;
     }
     keys[i] = k;
   }
-  bitonic_sort(keys, len_pow2);
+  if (!keep_src) bitonic_sort(keys, len_pow2); else __syncthreads();
   for (int i = tid; i < n; i += kSortThreads) {
     const unsigned o = keys[i] & 8191u;
     sc.src_sorted[ss + i] = src[o];
@@ -667,7 +713,9 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   // 1. sort
   int len = 64;
   while (len < max_src_n || len < max_tgt_n) len <<= 1;
-  hipLaunchKernelGGL(icp_sort_kernel, dim3(S), dim3(kSortThreads), sizeof(unsigned) * (size_t)len, stream, a, sc, len);
+  int keep = -1;                                             // −1: decided per cloud (icp_sort_kernel); 0–3: bit 0 / 1 keeps the target / source order
+  if (const char* env = getenv("LSLAM_ICP_PRUNE_KEEP")) keep = atoi(env);
+  hipLaunchKernelGGL(icp_sort_kernel, dim3(S), dim3(kSortThreads), sizeof(unsigned) * (size_t)len, stream, a, sc, len, keep);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // 2. iterate
@@ -719,9 +767,9 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   };
   if ((a.src64 == nullptr) != (a.tgt64 == nullptr)) return hipErrorInvalidValue;
   // per-lane lists (LIST) against whole-wave chunk evaluation, same box: C4 22.4 vs 24.1 ms, float64-exact 23.9 vs 27.5 ms;
-  // the LiDAR-sized C3 batch 2.23 vs 2.55 ms in float64-exact mode but 1.98 vs 1.91 ms in float32 (few chunks, short lists:
-  // the gathered reads' latency is not hidden)
-  bool list = a.src64 != nullptr || max_src_n >= 2048;
+  // the LiDAR-sized C3 batch in beam order 1.21 vs 1.37 ms (float64-exact 1.53 vs 2.12 ms).  Only Morton-sorted clouds of
+  // LiDAR size in float32 are 3 % slower with lists (1.98 vs 1.91 ms): not worth a second rule
+  bool list = true;
   if (const char* env = getenv("LSLAM_ICP_PRUNE_LIST")) list = atoi(env) != 0;
   if (list) {
     if (a.src64) {

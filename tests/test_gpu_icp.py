@@ -478,9 +478,12 @@ def test_loop_closure_batch_matches_per_pair_reference_semantics(icp, tmp_path, 
     assert np.load(paths[0]).shape == (32, 3) and np.load(paths[1]).shape == (31, 3, 3)
 
 
-def test_exact_pruning_gives_the_brute_force_answers(icp, prec):
+@pytest.mark.parametrize("plist", ["1", "0"])
+def test_exact_pruning_gives_the_brute_force_answers(icp, prec, plist, monkeypatch):
     """LSLAM_ICP_PRUNE: Morton-sorted clouds + box tests must not change a single correspondence or
-    iteration count (duplicates, ragged sizes, several passes per problem, normalised error)"""
+    iteration count (duplicates, ragged sizes, several passes per problem, normalised error) — with the chunks evaluated
+    by the whole wave (plist 0) and from per-lane lists (plist 1; the launcher picks by size and precision mode)"""
+    monkeypatch.setenv("LSLAM_ICP_PRUNE_LIST", plist)
     from lidar_slam_amd.batch import icp_batch
     from lidar_slam_amd.synth import batch_c4
     pack_clouds = prec.pack
@@ -526,9 +529,11 @@ def test_exact_pruning_gives_the_brute_force_answers(icp, prec):
     np.testing.assert_array_equal(b.T, a.T)
 
 
-def test_pruning_on_degenerate_clouds_with_massive_ties(icp, prec):
+@pytest.mark.parametrize("plist", ["1", "0"])
+def test_pruning_on_degenerate_clouds_with_massive_ties(icp, prec, plist, monkeypatch):
     """lattices, coincident points, a cloud collapsed to one point: every tie must still resolve to the
-    lowest ORIGINAL index, exactly as the all-pairs sweep does"""
+    lowest ORIGINAL index, exactly as the all-pairs sweep does (both ways of evaluating the surviving chunks)"""
+    monkeypatch.setenv("LSLAM_ICP_PRUNE_LIST", plist)
     from lidar_slam_amd.batch import icp_batch
     pack_clouds = prec.pack
     rng = np.random.default_rng(5)
