@@ -638,6 +638,21 @@ def other_config(name, a, torch, device, stream, timed):
             res32["r"] = scan_matching_relative_poses(seq.x_ts, z32, return_info=True)        # float32 scans: float32 search only
         stage32_s = min(_wall(stage32) for _ in range(3))
         rel32, info32 = res32["r"]
+        # the kernels alone: the same batch with the scans already resident in HBM (what a pipeline that keeps its scans on the device pays)
+        from lidar_slam_amd.modules.localization import relative_pose_guesses
+        pts64, off = B.pack_clouds([np.asarray(z, dtype=np.float64) for z in seq.z_ts], dtype=np.float64)
+        d64 = torch.from_numpy(pts64).to(device); d32 = d64.to(torch.float32); d_off = torch.from_numpy(off).to(device)
+        d_init = torch.from_numpy(relative_pose_guesses(seq.x_ts)).to(device)
+        Sq, maxn = len(seq.z_ts) - 1, int(np.diff(off).max())
+        oT = torch.empty((Sq, 4, 4), dtype=torch.float64, device=device); oe = torch.empty(Sq, dtype=torch.float64, device=device)
+        oi = torch.empty(Sq, dtype=torch.int32, device=device)
+        def resident(f64):
+            B.icp_batch_dev(d32.data_ptr(), d_off.data_ptr() + 8, d32.data_ptr(), d_off.data_ptr(), 2, d_init.data_ptr(), Sq, maxn, maxn,
+                            oT.data_ptr(), oe.data_ptr(), oi.data_ptr(), None, epsilon=0.001, max_iters=2000, stopping_thresh=1e-4, stream=stream,
+                            d_src64=d64.data_ptr() if f64 else None, d_tgt64=d64.data_ptr() if f64 else None)
+        kern64_ms = _time(torch, lambda: resident(True), 2, 8)
+        assert int(oi.sum().item()) == int(info.iterations.sum())
+        kern32_ms = _time(torch, lambda: resident(False), 2, 8)
         # CPU baseline on a bounded sample of the same sequence (oracle KDTree port = reference algorithm)
         from oracle import se2_oracle
         n = 400
@@ -646,7 +661,8 @@ def other_config(name, a, torch, device, stream, timed):
         cpu_s = time.perf_counter() - t0
         same = int(np.sum(info.iterations[:n] == it_cpu))
         out = {"workload": "C3 dataset-20-like sequence: 4955 consecutive scan pairs (650-1081 pts), natural convergence, host arrays in/out (PCIe + chain included)",
-               "stage_seconds": stage_s, "stage_seconds_first_call": first_s, "stage_seconds_float32_scans": stage32_s, "iteration_counts_differ_float32_vs_float64_exact": int(np.sum(info.iterations != info32.iterations)),
+               "stage_seconds": stage_s, "stage_seconds_first_call": first_s, "stage_seconds_float32_scans": stage32_s,
+               "kernel_seconds_scans_resident": kern64_ms * 1e-3, "kernel_seconds_scans_resident_float32": kern32_ms * 1e-3, "iteration_counts_differ_float32_vs_float64_exact": int(np.sum(info.iterations != info32.iterations)),
                "max_rel_pose_difference_float32_vs_float64_exact": float(np.abs(rel - rel32).max()),
                "scan_pairs_per_sec": 4955 / stage_s, "total_iterations": int(info.iterations.sum()),
                "cpu_port_seconds_per_pair": cpu_s / n, "cpu_port_extrapolated_seconds": cpu_s / n * 4955,

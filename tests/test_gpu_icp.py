@@ -529,6 +529,42 @@ def test_exact_pruning_gives_the_brute_force_answers(icp, prec, plist, monkeypat
     np.testing.assert_array_equal(b.T, a.T)
 
 
+@pytest.mark.parametrize("keep", ["auto", "0", "1", "2", "3"])
+def test_pruned_search_is_exact_for_any_point_order(icp, prec, keep, monkeypatch):
+    """the pruned batch path keeps a cloud in the order it arrives when that order is compact (LiDAR beam order) and
+    Morton-sorts it otherwise: scans in beam order, the same scans shuffled, one of each, collinear and single-point clouds —
+    the decision (auto) and every forced combination (bit 0: target as given, bit 1: source as given) must give the all-pairs
+    sweep's correspondences and iteration counts"""
+    from lidar_slam_amd.batch import icp_batch
+    from lidar_slam_amd.synth import sequence_c3
+    from lidar_slam_amd.modules.localization import relative_pose_guesses
+    pack_clouds = prec.pack
+    if keep != "auto":
+        monkeypatch.setenv("LSLAM_ICP_PRUNE_KEEP", keep)
+    rng = np.random.default_rng(2024)
+    seq = sequence_c3(9, seed=11)
+    scans = [np.asarray(z, dtype=np.float64) for z in seq.z_ts]
+    init = list(relative_pose_guesses(seq.x_ts))                      # pair i: scan i+1 onto scan i
+    srcs, tgts = [z for z in scans[1:]], [z for z in scans[:-1]]
+    for k in (1, 4):                                                   # source shuffled
+        srcs[k] = srcs[k][rng.permutation(srcs[k].shape[0])]
+    for k in (2, 4):                                                   # target shuffled
+        tgts[k] = tgts[k][rng.permutation(tgts[k].shape[0])]
+    line = np.column_stack((np.linspace(-3, 5, 700), np.full(700, 0.25)))
+    srcs += [line[:650] + [0.01, 0.0], line[rng.permutation(700)], np.array([[0.5, 0.5]] * 80)]
+    tgts += [line, line + [0.0, 0.02], np.array([[0.6, 0.4]] * 70)]
+    init += [np.eye(4)] * 3
+    fs, so = pack_clouds(srcs)
+    ft, to = pack_clouds(tgts)
+    I = np.stack(init)
+    kw = dict(epsilon=1e-3, return_correspondences=True)
+    a = icp_batch(fs, so, ft, to, I, prune=False, **kw)
+    b = icp_batch(fs, so, ft, to, I, prune=True, **kw)
+    np.testing.assert_array_equal(b.iterations, a.iterations)
+    np.testing.assert_array_equal(b.correspondences, a.correspondences)
+    np.testing.assert_allclose(b.T, a.T, atol=1e-10)
+
+
 @pytest.mark.parametrize("plist", ["1", "0"])
 def test_pruning_on_degenerate_clouds_with_massive_ties(icp, prec, plist, monkeypatch):
     """lattices, coincident points, a cloud collapsed to one point: every tie must still resolve to the

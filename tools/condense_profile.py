@@ -51,7 +51,7 @@ out = {}
 fetch, _ = counters("pmc_fetch")
 write, _ = counters("pmc_write")
 sq, dur = counters("pmc_sq")
-for tag, needle in (("c4", "icp_batch_filter_kernel<2, 8, false>"), ("c4_default_search_strategy", "icp_pruned_kernel<1, false>"), ("c4_float64_exact", "icp_pruned_kernel<1, true>"), ("c4_sort", "icp_sort_kernel")):
+for tag, needle in (("c4", "icp_batch_filter_kernel<2, 8, false>"), ("c4_default_search_strategy", "icp_pruned_kernel<1, false, true>"), ("c4_float64_exact", "icp_pruned_kernel<1, true, true>"), ("c4_sort", "icp_sort_kernel")):
     kf, kw, ks = pick(fetch, needle), pick(write, needle), pick(sq, needle)
     if not (kf and kw and ks):
         continue
