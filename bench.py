@@ -344,7 +344,7 @@ def main():
                          "device_valu_probe_lane_ops_per_s": issue_rate,
                          "kernel_valu_instructions_per_pair_eval": prof.get("lane_ops_per_pair_eval"), "profile": prof.get("source"),
                          "peak_is": "fp32 vector FMA peak = the guide's dense f32 MFMA peak (157.3 TFLOP/s); no MFMA is used", "note": "float32 VALU-issue bound: the all-pairs sweep runs out of LDS (expanded form |t|^2 - 2a.t = 2 v_fma + 1 min per pair, "
-                                 "then the exact recipe on the chunks the rounding bound cannot exclude); HBM sees only the compulsory bytes. "
+                                 "then the exact recipe on the chunks the rounding bound cannot exclude); HBM reads are the two clouds, the rest of `traffic` is register-spill write-back (25 registers of the 128-VGPR build, ~6 GB/s: off the critical path). "
                                  "peak = fp32 vector FMA peak; v_min3_f32 issues at half rate on gfx950 (profiles/r02/valu_probe2.txt), so 3 issue slots per pair is the floor of this form"},
             # the same launch priced against the HBM roof, as the bench contract words it (algorithmic bytes / duration): four orders away, not the binding roof
             "roofline_hbm": {"kernel": headline_kernel(S, P), "bound": "hbm", "achieved": (2 * S * P * 8 + S * 2 * 128) / (kernel_ms * 1e-3) / 1e9,
