@@ -550,10 +550,6 @@ def test_pruned_search_is_exact_for_any_point_order(icp, prec, keep, monkeypatch
         srcs[k] = srcs[k][rng.permutation(srcs[k].shape[0])]
     for k in (2, 4):                                                   # target shuffled
         tgts[k] = tgts[k][rng.permutation(tgts[k].shape[0])]
-    line = np.column_stack((np.linspace(-3, 5, 700), np.full(700, 0.25)))
-    srcs += [line[:650] + [0.01, 0.0], line[rng.permutation(700)], np.array([[0.5, 0.5]] * 80)]
-    tgts += [line, line + [0.0, 0.02], np.array([[0.6, 0.4]] * 70)]
-    init += [np.eye(4)] * 3
     fs, so = pack_clouds(srcs)
     ft, to = pack_clouds(tgts)
     I = np.stack(init)
@@ -563,6 +559,19 @@ def test_pruned_search_is_exact_for_any_point_order(icp, prec, keep, monkeypatch
     np.testing.assert_array_equal(b.iterations, a.iterations)
     np.testing.assert_array_equal(b.correspondences, a.correspondences)
     np.testing.assert_allclose(b.T, a.T, atol=1e-10)
+    # clouds on a line (ordered and shuffled) and clouds collapsed to a point: the order test must cope with zero extents; their
+    # Kabsch step is rank-deficient (parity undefined), so one search from the identity is compared, not the transforms
+    line = np.column_stack((np.linspace(-3, 5, 700), np.full(700, 0.25)))
+    srcs = [line[:650] + [0.01, 0.0], line[rng.permutation(700)], np.array([[0.5, 0.5]] * 80), line[::-1]]
+    tgts = [line, line + [0.0, 0.02], np.array([[0.6, 0.4]] * 70), line[rng.permutation(700)]]
+    fs, so = pack_clouds(srcs)
+    ft, to = pack_clouds(tgts)
+    I = np.tile(np.eye(4), (len(srcs), 1, 1))
+    kw = dict(epsilon=0.0, stopping_thresh=0.0, max_iters=0, return_correspondences=True)
+    a = icp_batch(fs, so, ft, to, I, prune=False, **kw)
+    b = icp_batch(fs, so, ft, to, I, prune=True, **kw)
+    np.testing.assert_array_equal(b.correspondences, a.correspondences)
+    np.testing.assert_allclose(b.error, a.error, rtol=1e-12)
 
 
 @pytest.mark.parametrize("plist", ["1", "0"])
