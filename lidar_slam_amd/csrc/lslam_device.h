@@ -244,6 +244,37 @@ __device__ __forceinline__ void filter_decide(const float (&a)[DIM], float Rt, f
   third = !(s3 > lim) || !(Rt < 1e15f) || !(an < 1e15f);
 }
 
+// Position of grid cell c[0..DIM) (BITS bits per axis) along the DIM-dimensional Hilbert curve, DIM·BITS bits (Skilling's
+// transpose form, then the bits of the axes interleaved, axis 0 leading).  Consecutive cells share a face: a run of
+// consecutive points never bridges two distant parts of the cloud the way it does where the Z curve jumps.
+template <int DIM, int BITS>
+__device__ __forceinline__ unsigned hilbert_key(const unsigned (&c)[DIM]) {
+  unsigned X[DIM];
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) X[i] = c[i];
+  constexpr unsigned M = 1u << (BITS - 1);
+  for (unsigned Q = M; Q > 1; Q >>= 1) {                       // inverse undo
+    const unsigned Pm = Q - 1;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+      if (X[i] & Q) X[0] ^= Pm;
+      else { const unsigned t = (X[0] ^ X[i]) & Pm; X[0] ^= t; X[i] ^= t; }
+    }
+  }
+#pragma unroll
+  for (int i = 1; i < DIM; ++i) X[i] ^= X[i - 1];              // Gray encode
+  unsigned t = 0;
+  for (unsigned Q = M; Q > 1; Q >>= 1)
+    if (X[DIM - 1] & Q) t ^= Q - 1;
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) X[i] ^= t;
+  unsigned key = 0;
+  for (int b = BITS - 1; b >= 0; --b)
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) key = (key << 1) | ((X[i] >> b) & 1u);
+  return key;
+}
+
 // Accumulator slots of one (p, q) pair stream, in the order they are reduced.
 //   planar: n, Σp(2), Σq(2), Σpqᵀ(4), sse            = 10   (+4 bbox when normalising)
 //   3-D   : n, Σp(3), Σq(3), Σpqᵀ(9), sse            = 17   (+6 bbox)

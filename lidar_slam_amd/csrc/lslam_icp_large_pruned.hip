@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <cstdlib>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -84,18 +85,20 @@ __global__ void lp_bbox_finish_kernel(const float* __restrict__ partial, int par
 template <int DIM>
 __global__ void __launch_bounds__(kLpThreads)
 lp_keys_kernel(const float* __restrict__ pts, int64_t n, const float* __restrict__ grid, LpT T, unsigned* __restrict__ keys,
-               unsigned* __restrict__ vals) {
+               unsigned* __restrict__ vals, int curve) {
   const int64_t i = (int64_t)blockIdx.x * kLpThreads + threadIdx.x;
   if (i >= n) return;
   float p[3] = {pts[i * DIM], pts[i * DIM + 1], DIM == 3 ? pts[i * DIM + 2] : 0.f};
-  unsigned key = 0;
+  unsigned key = 0, cell[DIM];
 #pragma unroll
   for (int d = 0; d < DIM; ++d) {
     const float v = T.m[d][0] * p[0] + T.m[d][1] * p[1] + T.m[d][2] * p[2] + T.m[d][3];
     int c = (int)((v - grid[d]) * grid[3 + d]);
     c = min(max(c, 0), (1 << kLpAxisBits) - 1);
+    cell[d] = (unsigned)c;
     key |= spread10((unsigned)c, DIM) << d;
   }
+  if (curve == 1) key = hilbert_key<DIM, kLpAxisBits>(cell);   // the cells along the Hilbert curve instead of the Z curve
   keys[i] = key;
   vals[i] = (unsigned)i;
 }
@@ -550,7 +553,9 @@ template <int DIM>
 static hipError_t lp_sort_cloud(const float* pts, int64_t n, const float* d_grid, const LpT& T, const LpWs& ws, void* sorted,
                                 int32_t* index, hipStream_t st) {
   using SP = typename SortedPoint<DIM>::type;
-  hipLaunchKernelGGL(lp_keys_kernel<DIM>, dim3(lp_blocks(n)), dim3(kLpThreads), 0, st, pts, n, d_grid, T, ws.keys_in, ws.vals_in);
+  int curve = 1;
+  if (const char* env = getenv("LSLAM_ICP_PRUNE_CURVE")) curve = atoi(env);
+  hipLaunchKernelGGL(lp_keys_kernel<DIM>, dim3(lp_blocks(n)), dim3(kLpThreads), 0, st, pts, n, d_grid, T, ws.keys_in, ws.vals_in, curve);
   size_t tb = ws.temp_bytes;
   hipError_t e = rocprim::radix_sort_pairs(ws.temp, tb, ws.keys_in, ws.keys_out, ws.vals_in, ws.vals_out, (size_t)n, 0, DIM * kLpAxisBits, st);
   if (e != hipSuccess) return e;

@@ -63,7 +63,7 @@ __device__ inline void bitonic_sort3(unsigned* keys, int len) {
 
 // One workgroup per problem: Morton-sorted copies of target and source (float4: x, y, z, 0) + their original indices.
 __global__ void __launch_bounds__(kSort3Threads)
-icp_sort3_kernel(IcpBatchArgs a, PruneScratch3 sc, int len_pow2) {
+icp_sort3_kernel(IcpBatchArgs a, PruneScratch3 sc, int len_pow2, int curve) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned* keys = reinterpret_cast<unsigned*>(smem);
   __shared__ float sbox[6];
@@ -100,6 +100,7 @@ icp_sort3_kernel(IcpBatchArgs a, PruneScratch3 sc, int len_pow2) {
   auto cell_of = [&](float x, float y, float z) -> unsigned {
     int gx = (int)((x - lo[0]) * sc3[0]), gy = (int)((y - lo[1]) * sc3[1]), gz = (int)((z - lo[2]) * sc3[2]);
     gx = min(max(gx, 0), G - 1); gy = min(max(gy, 0), G - 1); gz = min(max(gz, 0), G - 1);
+    if (curve == 1) { const unsigned c[3] = {(unsigned)gx, (unsigned)gy, (unsigned)gz}; return hilbert_key<3, 4>(c); }   // (G = 8: the curve of the coarser grid, cells doubled)
     return morton4x3((unsigned)gx, (unsigned)gy, (unsigned)gz);
   };
 
@@ -494,7 +495,9 @@ bool icp_pruned3_supported(int64_t max_src_n, int64_t max_tgt_n) {
 hipError_t launch_icp_pruned3(IcpBatchArgs a, const PruneScratch3& sc, int S, int64_t max_src_n, int64_t max_tgt_n, hipStream_t stream) {
   int len = 64;
   while (len < max_src_n || len < max_tgt_n) len <<= 1;
-  hipLaunchKernelGGL(icp_sort3_kernel, dim3(S), dim3(kSort3Threads), sizeof(unsigned) * (size_t)len, stream, a, sc, len);
+  int curve = 1;
+  if (const char* env = getenv("LSLAM_ICP_PRUNE_CURVE")) curve = atoi(env);
+  hipLaunchKernelGGL(icp_sort3_kernel, dim3(S), dim3(kSort3Threads), sizeof(unsigned) * (size_t)len, stream, a, sc, len, curve);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   int P = 1;
