@@ -94,12 +94,25 @@ __device__ inline void bitonic_sort(unsigned* keys, int len) {
 // chunk boxes sum to no more than that figure (+ 2(W+H) for clouds on a line).  On the C3 sequence this takes the batch from
 // 1.94 to 1.29 ms: the two bitonic sorts were a quarter of it, and the search itself is faster on beam order.  The search
 // is exact for any order; the order only decides how much is pruned.
+// How it is sorted (round 3): each cloud is read from memory ONCE into LDS; a counting sort by cell (histogram with LDS atomics,
+// a scan, a scatter whose order inside a cell is arbitrary, then every cell's few points put in index order by one thread) replaces
+// the bitonic sort of (cell, index) keys — the same final order, so the same bits downstream.  Round 2's kernel moved 3.5× the
+// clouds through HBM (three passes + a gather of 8 bytes per cache line) and spent 78 barrier-separated steps per sort.  A cell
+// holding more than kSortCellMax points (collapsed or very uneven clouds) sends that cloud to the bitonic sort.
+constexpr int kSortCellMax = 48;
 __global__ void __launch_bounds__(kSortThreads)
-icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, int curve) {
+icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, int curve, int cap, int cur_words) {
+  // LDS sized by the launch for the batch's largest cloud (cap points, cur_words counters ≥ cells + 1 and ≥ len_pow2 keys):
+  // LiDAR-sized batches keep seven workgroups per CU, 4096-point clouds two
   extern __shared__ __align__(16) unsigned char smem[];
-  unsigned* keys = reinterpret_cast<unsigned*>(smem);
+  float2* pts = reinterpret_cast<float2*>(smem);                                     // the cloud as it arrives
+  unsigned* cur = reinterpret_cast<unsigned*>(smem + sizeof(float2) * (size_t)cap);  // per cell: count → start → end; the bitonic keys alias it
+  uint16_t* cell = reinterpret_cast<uint16_t*>(cur + cur_words);                     // cell of every point
+  uint16_t* ord = cell + cap;                                                        // ord[position] = original index
+  unsigned* keys = cur;
   __shared__ float sbox[4];
   __shared__ float red[kSortThreads / 64][4];
+  __shared__ unsigned sred[kSortThreads / 64 + 1];
   const int pair = blockIdx.x;
   const int tid = threadIdx.x;
   const int64_t s0 = a.src_off[pair], t0 = a.tgt_off[pair];
@@ -110,8 +123,8 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, 
   // start anywhere in a larger packed buffer, the scratch is sized for this batch only
   const int64_t ss = (int64_t)pair * sc.src_stride, ts = (int64_t)pair * sc.tgt_stride;
 
-  // bounding box of a cloud, the same four numbers in every thread
-  auto cloud_box = [&](const float2* pts, int cnt, float& x0, float& y0, float& x1, float& y1) {
+  // bounding box of the staged cloud, the same four numbers in every thread
+  auto cloud_box = [&](int cnt, float& x0, float& y0, float& x1, float& y1) {
     x0 = INFINITY; y0 = INFINITY; x1 = -INFINITY; y1 = -INFINITY;
     for (int j = tid; j < cnt; j += kSortThreads) {
       const float2 q = pts[j];
@@ -130,8 +143,8 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, 
     __syncthreads();
     x0 = sbox[0]; y0 = sbox[1]; x1 = sbox[2]; y1 = sbox[3];
   };
-  // does the cloud arrive in a compact order?  (fixed reduction order: the same answer in every run)
-  auto compact_as_given = [&](const float2* pts, int cnt, float w, float h) -> bool {
+  // does the staged cloud arrive in a compact order?  (fixed reduction order: the same answer in every run)
+  auto compact_as_given = [&](int cnt, float w, float h) -> bool {
     float sum = 0.f;
     for (int c = tid; c * kPruneChunk < cnt; c += kSortThreads) {
       float cx0 = INFINITY, cy0 = INFINITY, cx1 = -INFINITY, cy1 = -INFINITY;
@@ -155,13 +168,17 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, 
     return sbox[0] != 0.f;
   };
 
+  // ---- the target: staged, its box is the grid of both clouds ----
+  for (int j = tid; j < m; j += kSortThreads) pts[j] = tgt[j];
+  __syncthreads();
   float x0, y0, x1, y1;
-  cloud_box(tgt, m, x0, y0, x1, y1);
-  const bool keep_tgt = keep_forced >= 0 ? (keep_forced & 1) != 0 : compact_as_given(tgt, m, x1 - x0, y1 - y0);
+  cloud_box(m, x0, y0, x1, y1);
+  const bool keep_tgt = keep_forced >= 0 ? (keep_forced & 1) != 0 : compact_as_given(m, x1 - x0, y1 - y0);
   // about one point per cell on the Hilbert curve (≤ 64 cells per axis: 12 + 13 key bits; 1 % better than four per cell on C4);
   // the Z-curve keys of round 2 hold 5 bits per axis
   int G = m >= 2048 ? 32 : (m >= 512 ? 16 : 8);
   if (curve >= 1) G *= 2;
+  const int ncell = G * G;
   const float sx = (x1 > x0) ? (float)G / (x1 - x0) : 0.f, sy = (y1 > y0) ? (float)G / (y1 - y0) : 0.f;
   auto cell_of = [&](float x, float y) -> unsigned {
     int gx = (int)((x - x0) * sx), gy = (int)((y - y0) * sy);
@@ -169,43 +186,89 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, 
     if (curve >= 1) return hilbert_index((unsigned)gx, (unsigned)gy, (unsigned)G);
     return morton5((unsigned)gx, (unsigned)gy);
   };
+  const double* T = a.init_T + (int64_t)16 * pair;
+  const float t00 = (float)T[0], t01 = (float)T[1], t03 = (float)T[3], t10 = (float)T[4], t11 = (float)T[5], t13 = (float)T[7];
 
-  // ---- target ----
-  __syncthreads();
-  for (int j = tid; j < len_pow2; j += kSortThreads) {
-    unsigned k = 0xffffffffu;
-    if (j < m) { const float2 q = tgt[j]; k = (keep_tgt ? 0u : (cell_of(q.x, q.y) << 13)) | (unsigned)j; }
-    keys[j] = k;
-  }
-  if (!keep_tgt) bitonic_sort(keys, len_pow2); else __syncthreads();
+  // ord[] for the staged cloud of cnt points: by (cell, index); `placed`: the cell is taken of the point moved by the initial transform
+  auto order_by_cell = [&](int cnt, bool placed) {
+    for (int c = tid; c <= ncell; c += kSortThreads) cur[c] = 0u;
+    __syncthreads();
+    for (int j = tid; j < cnt; j += kSortThreads) {
+      const float2 p = pts[j];
+      const unsigned c = placed ? cell_of(t00 * p.x + t01 * p.y + t03, t10 * p.x + t11 * p.y + t13) : cell_of(p.x, p.y);
+      cell[j] = (uint16_t)c;
+      atomicAdd(&cur[c], 1u);
+    }
+    __syncthreads();
+    // counts → starts (exclusive scan over the cells; every thread owns `per` consecutive cells), and the fullest cell
+    const int per = (ncell + kSortThreads - 1) / kSortThreads;
+    unsigned mine = 0, most = 0;
+    for (int k = 0; k < per; ++k) { const int c = tid * per + k; if (c < ncell) { mine += cur[c]; most = max(most, cur[c]); } }
+    unsigned incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += up; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) most = max(most, (unsigned)__shfl_xor((int)most, o, 64));
+    if ((tid & 63) == 63) sred[tid >> 6] = incl;
+    if ((tid & 63) == 0) red[tid >> 6][1] = __uint_as_float(most);
+    __syncthreads();
+    unsigned before = incl - mine;
+    for (int w = 0; w < (tid >> 6); ++w) before += sred[w];
+    unsigned fullest = 0;
+    for (int w = 0; w < kSortThreads / 64; ++w) fullest = max(fullest, __float_as_uint(red[w][1]));
+    if (fullest > (unsigned)kSortCellMax) {
+      // collapsed / very uneven cloud: the bitonic sort of (cell, index) keys (they alias the counters, which are done with)
+      __syncthreads();
+      for (int j = tid; j < len_pow2; j += kSortThreads) keys[j] = j < cnt ? ((unsigned)cell[j] << 13) | (unsigned)j : 0xffffffffu;
+      bitonic_sort(keys, len_pow2);
+      for (int j = tid; j < cnt; j += kSortThreads) ord[j] = (uint16_t)(keys[j] & 8191u);
+      __syncthreads();
+      return;
+    }
+    for (int k = 0; k < per; ++k) {                            // in place: cur[c] = first position of cell c
+      const int c = tid * per + k;
+      if (c < ncell) { const unsigned cnt_c = cur[c]; cur[c] = before; before += cnt_c; }
+    }
+    __syncthreads();
+    for (int j = tid; j < cnt; j += kSortThreads) ord[atomicAdd(&cur[cell[j]], 1u)] = (uint16_t)j;      // cur[c] ends as the END of cell c
+    __syncthreads();
+    // inside a cell the scatter's order is whoever came first: put every cell's points in index order (insertion sort, ≤ kSortCellMax)
+    for (int c = tid; c < ncell; c += kSortThreads) {
+      const int b = c ? (int)cur[c - 1] : 0, e = (int)cur[c];
+      for (int i = b + 1; i < e; ++i) {
+        const uint16_t v = ord[i];
+        int k = i - 1;
+        while (k >= b && ord[k] > v) { ord[k + 1] = ord[k]; --k; }
+        ord[k + 1] = v;
+      }
+    }
+    __syncthreads();
+  };
+
+  if (keep_tgt) { for (int j = tid; j < m; j += kSortThreads) ord[j] = (uint16_t)j; __syncthreads(); }
+  else order_by_cell(m, false);
   for (int j = tid; j < m; j += kSortThreads) {
-    const unsigned o = keys[j] & 8191u;
-    sc.tgt_sorted[ts + j] = tgt[o];
+    const unsigned o = ord[j];
+    sc.tgt_sorted[ts + j] = pts[o];
     sc.tgt_index[ts + j] = (uint16_t)o;
     if (a.tgt64) sc.tgt64_sorted[ts + j] = reinterpret_cast<const double2*>(a.tgt64)[t0 + o];
   }
-  // ---- source: as given if compact (a rigid motion does not undo that), else placed by its initial transform into the target's grid ----
+  __syncthreads();
+
+  // ---- the source: as given if compact (a rigid motion does not undo that), else placed by its initial transform into the target's grid ----
+  for (int i = tid; i < n; i += kSortThreads) pts[i] = src[i];
+  __syncthreads();
   bool keep_src = keep_forced >= 0 ? (keep_forced & 2) != 0 : false;
   if (keep_forced < 0) {
     float u0, v0, u1, v1;
-    cloud_box(src, n, u0, v0, u1, v1);
-    keep_src = compact_as_given(src, n, u1 - u0, v1 - v0);
+    cloud_box(n, u0, v0, u1, v1);
+    keep_src = compact_as_given(n, u1 - u0, v1 - v0);
   }
-  __syncthreads();
-  const double* T = a.init_T + (int64_t)16 * pair;
-  const float t00 = (float)T[0], t01 = (float)T[1], t03 = (float)T[3], t10 = (float)T[4], t11 = (float)T[5], t13 = (float)T[7];
-  for (int i = tid; i < len_pow2; i += kSortThreads) {
-    unsigned k = 0xffffffffu;
-    if (i < n) {
-      const float2 p = src[i];
-      k = (keep_src ? 0u : (cell_of(t00 * p.x + t01 * p.y + t03, t10 * p.x + t11 * p.y + t13) << 13)) | (unsigned)i;
-    }
-    keys[i] = k;
-  }
-  if (!keep_src) bitonic_sort(keys, len_pow2); else __syncthreads();
+  if (keep_src) { for (int i = tid; i < n; i += kSortThreads) ord[i] = (uint16_t)i; __syncthreads(); }
+  else order_by_cell(n, true);
   for (int i = tid; i < n; i += kSortThreads) {
-    const unsigned o = keys[i] & 8191u;
-    sc.src_sorted[ss + i] = src[o];
+    const unsigned o = ord[i];
+    sc.src_sorted[ss + i] = pts[o];
     sc.src_index[ss + i] = (uint16_t)o;
     if (a.src64) sc.src64_sorted[ss + i] = reinterpret_cast<const double2*>(a.src64)[s0 + o];
   }
@@ -740,7 +803,18 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   // straddle a jump have boxes across half the cloud and survive the box tests of many waves: C4 22.5 -> 17.0 ms with Hilbert
   int curve = 1;
   if (const char* env = getenv("LSLAM_ICP_PRUNE_CURVE")) curve = atoi(env);
-  hipLaunchKernelGGL(icp_sort_kernel, dim3(S), dim3(kSortThreads), sizeof(unsigned) * (size_t)len, stream, a, sc, len, keep, curve);
+  // LDS of the sort: the staged cloud, a counter per cell (the bitonic keys of the fall-back alias them), cell and position per point
+  const int64_t big = max_src_n > max_tgt_n ? max_src_n : max_tgt_n;
+  const int cap = (int)(((big + 63) / 64) * 64);
+  int g_max = max_tgt_n >= 2048 ? 32 : (max_tgt_n >= 512 ? 16 : 8);
+  if (curve >= 1) g_max *= 2;
+  const int cur_words = ((g_max * g_max + 64 > len ? g_max * g_max + 64 : len) + 3) & ~3;
+  const size_t sort_lds = sizeof(float2) * (size_t)cap + sizeof(unsigned) * (size_t)cur_words + 2 * sizeof(uint16_t) * (size_t)cap;
+  {
+    hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(icp_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
+    if (ee != hipSuccess) return ee;
+  }
+  hipLaunchKernelGGL(icp_sort_kernel, dim3(S), dim3(kSortThreads), sort_lds, stream, a, sc, len, keep, curve, cap, cur_words);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // 2. iterate
