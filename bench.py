@@ -531,9 +531,11 @@ def other_config(name, a, torch, device, stream, timed):
         cpu_s = (time.perf_counter() - t0) / sum(r.iterations for r in sample)               # seconds per iteration of the port
         same = all(abs(found[0][3][k] - r.error) < 1e-4 * r.error and found[0][4][k] == r.iterations for k, r in zip((0, 8, 16), sample))
         register_multi_start_many(model, views)
-        t0 = time.perf_counter()
-        many = register_multi_start_many(model, views)
-        dt_many = time.perf_counter() - t0
+        dt_many = 1e9
+        for _ in range(3):                                   # a 6 ms call: the best of three (one shot caught a 10 ms outlier on one box)
+            t0 = time.perf_counter()
+            many = register_multi_start_many(model, views)
+            dt_many = min(dt_many, time.perf_counter() - t0)
         same_many = all(np.array_equal(a[0], b[0]) and a[1] == b[1] for a, b in zip(many, found)) if views[0].shape[0] * model.shape[0] <= 2_000_000 else \
             all(np.abs(a[0] - b[0]).max() < 1e-9 and abs(a[1] - b[1]) < 1e-9 * b[1] for a, b in zip(many, found))
         return {"workload": f"C1 drill-style registration: {len(views)} views ({views[0].shape[0]} pts) x 24 yaw starts of a {model.shape[0]}-pt model, "
