@@ -367,6 +367,26 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
     }
     aabb[c] = make_float4(x0, y0, x1, y1);
   }
+  // the box of every slab of 64·P consecutive sources, once per problem, in the sources' own frame: per iteration the wave's
+  // box is then the box of this box's four corners under T (interval arithmetic on a wave-uniform float4) instead of four
+  // 6-step reductions over the transformed points — 24 dependent cross-lane steps per slab and iteration were a fifth of the
+  // kernel's wave time.  It is a little larger than the exact box (by the rotation of T), which only lets a few more chunks
+  // through the wave-level test; every point is still tested on its own.
+  float4* slab_box = reinterpret_cast<float4*>(smem + lay.slab_off);
+  const int nslabs = (n + kWave * P - 1) / (kWave * P);
+  for (int sl = wave; sl < nslabs; sl += nwaves) {
+    float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = (sl * kWave + lane) * P + p;
+      if (i < n) {
+        const float2 v = src_lds ? sh_src[i] : ssrc[i];
+        x0 = fminf(x0, v.x); y0 = fminf(y0, v.y); x1 = fmaxf(x1, v.x); y1 = fmaxf(y1, v.y);
+      }
+    }
+    x0 = wave_min_f(x0); y0 = wave_min_f(y0); x1 = wave_max_f(x1); y1 = wave_max_f(y1);
+    if (lane == 0) slab_box[sl] = make_float4(x0, y0, x1, y1);
+  }
   __syncthreads();
   if constexpr (F64) {
     Rt = sqrtf(__int_as_float(sh_flag[1])) * 1.0001f;
@@ -400,7 +420,6 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
     // waited at the barrier for its slowest wave (C4: 22.8 -> 22.4 ms).  The matches go to LDS by source position, so who
     // searched a slab does not matter — but phase B then needs a barrier, which costs LiDAR-sized problems (one slab per
     // wave, nothing to balance) 10 %: they keep the fixed map.
-    const int nslabs = (n + kWave * P - 1) / (kWave * P);
     const bool take = nslabs > nwaves;
     for (int round = 0;; ++round) {
       int slab = wave + nwaves * round;
@@ -411,7 +430,6 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
       if (slab >= nslabs) break;
       const int base = (slab - wave) * kWave * P;            // base + tid·P + p = slab·64·P + lane·P + p
       float ax[P], ay[P];
-      float wx0 = INFINITY, wy0 = INFINITY, wx1 = -INFINITY, wy1 = -INFINITY;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int i = base + tid * P + p;
@@ -420,10 +438,22 @@ icp_pruned_kernel(IcpBatchArgs args, PruneScratch sc, PruneLayout lay) {
           const float2 v = src_lds ? sh_src[i] : ssrc[i];
           ax[p] = (float)(T[0][0] * (double)v.x + T[0][1] * (double)v.y + T[0][3]);      // icp.py:116
           ay[p] = (float)(T[1][0] * (double)v.x + T[1][1] * (double)v.y + T[1][3]);
-          wx0 = fminf(wx0, ax[p]); wy0 = fminf(wy0, ay[p]); wx1 = fmaxf(wx1, ax[p]); wy1 = fmaxf(wy1, ay[p]);
         }
       }
-      wx0 = wave_min_f(wx0); wy0 = wave_min_f(wy0); wx1 = wave_max_f(wx1); wy1 = wave_max_f(wy1);
+      // the wave's box: the slab's box under T, widened by 16 ulps of the magnitudes involved (the points above are rounded from
+      // float64, the corners here are float32 products)
+      float wx0, wy0, wx1, wy1;
+      {
+        const float4 sb = slab_box[slab];
+        const float r00 = (float)T[0][0], r01 = (float)T[0][1], r03 = (float)T[0][3], r10 = (float)T[1][0], r11 = (float)T[1][1], r13 = (float)T[1][3];
+        const float mx = fmaxf(fabsf(sb.x), fabsf(sb.z)), my = fmaxf(fabsf(sb.y), fabsf(sb.w));
+        const float ex = 1e-6f * (fabsf(r00) * mx + fabsf(r01) * my + fabsf(r03)) + 1e-30f;
+        const float ey = 1e-6f * (fabsf(r10) * mx + fabsf(r11) * my + fabsf(r13)) + 1e-30f;
+        wx0 = r03 + fminf(r00 * sb.x, r00 * sb.z) + fminf(r01 * sb.y, r01 * sb.w) - ex;
+        wx1 = r03 + fmaxf(r00 * sb.x, r00 * sb.z) + fmaxf(r01 * sb.y, r01 * sb.w) + ex;
+        wy0 = r13 + fminf(r10 * sb.x, r10 * sb.z) + fminf(r11 * sb.y, r11 * sb.w) - ey;
+        wy1 = r13 + fmaxf(r10 * sb.x, r10 * sb.z) + fmaxf(r11 * sb.y, r11 * sb.w) + ey;
+      }
       PRUNE_MARK(0);
 
       bool tie = false;
@@ -833,6 +863,7 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
   size_t off = (size_t)padded * sizeof(float2);
   lay.aabb_off = (uint32_t)off; off += (size_t)nchunks * sizeof(float4);
+  lay.slab_off = (uint32_t)off; off += (size_t)((max_src_n + 64 * P - 1) / (64 * P)) * sizeof(float4);
   lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(float2));
   lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));
   lay.red_off = (uint32_t)off;

@@ -75,7 +75,7 @@ struct PruneScratch {                      // Morton-sorted copies: problem k ow
   // them sequentially / from neighbouring lines instead of gathering 16 bytes per point from the caller's order
   double2* src64_sorted; double2* tgt64_sorted;
 };
-struct PruneLayout { uint32_t aabb_off, src_off, prev_off, red_off; unsigned* debug_counter; };
+struct PruneLayout { uint32_t aabb_off, src_off, prev_off, red_off; unsigned* debug_counter; uint32_t slab_off; };   // slab_off: planar kernel only
 bool icp_pruned_supported(int dim, int64_t max_src_n, int64_t max_tgt_n);
 hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n,
                              hipStream_t stream);
