@@ -86,7 +86,8 @@ int         lslam_valu_probe(int device, double *out_lane_ops_per_s);
  *   all pairs   every source against every target out of LDS (the big batch build sweeps the expanded form
  *               |t|^2 - 2 a.t first and re-evaluates, with the exact recipe, only the chunks its rounding bound
  *               cannot exclude);
- *   pruning     both clouds are put into Morton order once per problem and every group of target points whose
+ *   pruning     both clouds are put into a spatial order once per problem (Hilbert curve of a grid; a cloud that arrives in a
+ *               compact order, e.g. LiDAR beam order, is kept as it is) and every group of target points whose
  *               bounding box cannot hold a nearer (or equally near) point for any source of a wave is skipped,
  *               with a float32-safe bound.  Batched entry points: planar problems of at most 4096 points per
  *               cloud, 3-D problems of at most 4096 target / 8191 source points; lslam_icp_large*: any size.
@@ -113,7 +114,7 @@ int lslam_icp_batch(const float *src, const int64_t *src_off,
  * Inputs are trusted to be finite and every target non-empty (the host entry
  * point validates; this one cannot without a synchronisation).
  * Enqueues on `stream` and returns — with two exceptions a caller overlapping streams must know: (1) the pruned
- * kernels keep Morton-sorted copies in a workspace of the calling thread; the first call at a larger size (more
+ * kernels keep spatially ordered copies in a workspace of the calling thread; the first call at a larger size (more
  * problems x points) re-allocates it behind a hipDeviceSynchronize(), and a call on a different stream than the
  * thread's previous workspace-using call waits (on the device) for that call; (2) the all-pairs sweep
  * (LSLAM_ICP_ALL_PAIRS, or the automatic choice for small clouds) uses no workspace and is never ordered or

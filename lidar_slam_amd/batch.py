@@ -197,7 +197,7 @@ def icp_batch_dev(d_src, d_src_off, d_tgt, d_tgt_off, dim, d_init_T, S, max_src_
 def icp_large_dev(d_src, n, d_tgt, m, dim, init_T, epsilon=0.01, max_iters=2000, stopping_thresh=0.0001,
                   normalize_error=False, d_out_corr=None, poll_every=8, stream=0, prune=None, d_src64=None, d_tgt64=None):
     """run_icp on one large cloud pair resident on the device; returns (T, error, iterations).
-    ``prune``: None = automatic, True = Morton-sorted clouds + a box hierarchy over the target, False = all pairs;
+    ``prune``: None = automatic, True = spatially ordered clouds (Hilbert curve) + a box hierarchy over the target, False = all pairs;
     exact results either way.  ``d_src64`` / ``d_tgt64``: the same clouds in float64 → float64-exact mode."""
     init_T = np.ascontiguousarray(init_T, dtype=np.float64).reshape(4, 4)
     out_T = np.empty((4, 4), dtype=np.float64)
