@@ -71,7 +71,7 @@ def register_multi_start(source_pc, target_pc, n_starts=24, epsilon=0.001, voxel
                         float(stopping_thresh), int(max_iters), ICP_NORMALIZE_ERROR, ptr(poses[k]),
                         ptr(errors[k:k + 1]), ptr(iters[k:k + 1]), None, icp._DEVICE))
     else:
-        r = icp_batch(np.tile(s32, (S, 1)), np.arange(S + 1, dtype=np.int64) * n, np.tile(t32, (S, 1)),
+        r = icp_batch(_tiled([s32], S, S * n, d, 0), np.arange(S + 1, dtype=np.int64) * n, _tiled([t32], S, S * m, d, 1),
                       np.arange(S + 1, dtype=np.int64) * m, init, epsilon=epsilon, max_iters=max_iters,
                       stopping_thresh=stopping_thresh, normalize_error=True, device=icp._DEVICE)
         poses, errors, iters = r.T, r.error, r.iterations
@@ -79,6 +79,22 @@ def register_multi_start(source_pc, target_pc, n_starts=24, epsilon=0.001, voxel
     out = (poses[best].copy(), np.float64(errors[best]))
     if return_all:
         out += (poses, errors, iters)
+    return out
+
+
+def _tiled(blocks, reps, total, d, slot):
+    """every block ``reps`` times in a row, packed — in pinned staging slot ``slot`` when the library can provide it"""
+    dtype = blocks[0].dtype
+    try:
+        from . import _lib
+        out = _lib.staging_array(slot, total * d, dtype).reshape(total, d)
+    except Exception:
+        out = np.empty((total, d), dtype=dtype)
+    at = 0
+    for b in blocks:
+        n = b.shape[0]
+        out[at:at + reps * n].reshape(reps, n, d)[:] = b
+        at += reps * n
     return out
 
 
@@ -103,10 +119,12 @@ def register_multi_start_many(source_pc, target_pcs, n_starts=24, epsilon=0.001,
         n_src.append(src_blocks[-1].shape[0]); n_tgt.append(tgt_blocks[-1].shape[0])
     if not targets:
         return []
-    src = np.vstack([np.tile(b, (n_starts, 1)) for b in src_blocks])
-    tgt = np.vstack([np.tile(b, (n_starts, 1)) for b in tgt_blocks])
     src_off = np.concatenate(([0], np.cumsum(np.repeat(n_src, n_starts)))).astype(np.int64)
     tgt_off = np.concatenate(([0], np.cumsum(np.repeat(n_tgt, n_starts)))).astype(np.int64)
+    # the n_starts copies of every cloud are written straight into the library's pinned staging buffers: the upload is then
+    # one DMA at PCIe speed (from a pageable vstack it ran at 6-10 GB/s, depending on the host: 2-4 ms for C1's 23 MB)
+    src = _tiled(src_blocks, n_starts, int(src_off[-1]), d, 0)
+    tgt = _tiled(tgt_blocks, n_starts, int(tgt_off[-1]), d, 1)
     r = icp_batch(src, src_off, tgt, tgt_off, np.concatenate(inits), epsilon=epsilon, max_iters=max_iters,
                   stopping_thresh=stopping_thresh, normalize_error=True, device=icp._DEVICE)
     out = []
