@@ -1,4 +1,4 @@
-// lslam_icp_pruned.hip — the batched planar ICP with EXACT chunk pruning (the default from 512 points per cloud).
+// lslam_icp_pruned.hip — the batched planar ICP with EXACT chunk pruning (the default from 256 points per cloud).
 //
 // Same operator, same results as icp_batch_kernel (modules/icp.py:123-189): every source point still
 // gets its exact float32 nearest target, lowest original index on ties.  What changes is how many

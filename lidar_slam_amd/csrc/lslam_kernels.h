@@ -63,7 +63,7 @@ struct IcpBatchTuning {
 // ---- exact chunk pruning (lslam_icp_pruned.hip) ----------------------------------------------------
 constexpr uint32_t kFlagPrune = 2u;        // == LSLAM_ICP_PRUNE
 constexpr uint32_t kFlagAllPairs = 4u;     // == LSLAM_ICP_ALL_PAIRS
-constexpr int64_t kAutoPruneBatchPoints = 512;          // automatic choice: batched planar problems from this many points per cloud
+constexpr int64_t kAutoPruneBatchPoints = 256;          // automatic choice: batched planar problems from this many points per cloud (profiles/r03/prune_threshold.txt: 0.142 vs 0.170 ms at 256, 0.109 vs 0.078 at 128)
 constexpr double kAutoPruneLargePairEvals3D = 1e9;      // one large pair: from this many pair evaluations per iteration (tools/prune_threshold.py)
 constexpr double kAutoPruneLargePairEvals2D = 2.5e8;
 constexpr int kPruneMaxPoints = 4096;      // per cloud: both sorted clouds + boxes + indices must fit LDS
