@@ -92,7 +92,7 @@ int         lslam_valu_probe(int device, double *out_lane_ops_per_s);
  *               with a float32-safe bound.  Batched entry points: planar problems of at most 4096 points per
  *               cloud, 3-D problems of at most 4096 target / 8191 source points; lslam_icp_large*: any size.
  * With neither bit set the library picks: pruning where it is supported and measured faster (batched planar
- * problems from 256 points per cloud, batched 3-D problems from 2000, one large pair from 2.5*10^8 (planar) / 10^9 (3-D) pair evaluations per
+ * problems from 256 points per cloud, batched 3-D problems from 256, one large pair from 2.5*10^8 (planar) / 10^9 (3-D) pair evaluations per
  * iteration; measured with tools/prune_threshold.py), all pairs elsewhere.
  * The environment variable LSLAM_ICP_PRUNE (0 / 1) changes that default; an explicit bit wins over it. */
 #define LSLAM_ICP_PRUNE 2u       /* force pruning (ignored where unsupported) */

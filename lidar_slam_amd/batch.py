@@ -150,7 +150,7 @@ def icp_batch(src, src_off, tgt, tgt_off, init_T, epsilon=0.01, max_iters=2000, 
     reference's float64 search (modules/icp.py:29-41), T / error agree with it to summation order.  float32 clouds
     (``lslam_icp_batch``) are searched as they are: exact float32 nearest neighbours.
     ``prune``: None = the library picks the search strategy (pruning for planar batches from 256 points per cloud and 3-D
-    batches from 2000), True = exact spatial pruning (planar problems of ≤ 4096 points per cloud, 3-D of ≤ 4096 target /
+    batches from 256), True = exact spatial pruning (planar problems of ≤ 4096 points per cloud, 3-D of ≤ 4096 target /
     8191 source points: both clouds sorted spatially, target chunks that provably cannot hold a nearer point skipped),
     False = the all-pairs sweep.  Same correspondences and
     iteration counts either way."""

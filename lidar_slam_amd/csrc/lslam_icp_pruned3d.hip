@@ -146,12 +146,40 @@ icp_sort3_kernel(IcpBatchArgs a, PruneScratch3 sc, int len_pow2, int curve) {
 }
 
 // F64: the float64-exact mode (lslam_device.h: NearTie), as in icp_pruned_kernel
-template <int P, bool F64>
+// One chunk of 16 sorted targets against ONE point of this lane, the chunk chosen by the lane (a gather; see prune_eval_chunk in
+// lslam_icp_pruned.hip): (bd, sec) = the smallest and second smallest distance over everything compared for the point so far,
+// at = the LDS address of the nearest target; lane l visits target (k XOR l) at step k, four reads in flight.
+constexpr int kTile3Align = kChunk3 * 16;
+__device__ __forceinline__ void prune3_eval_chunk(unsigned tile0, int chunk, int lane, const float (&a)[3], float& bd, float& sec, unsigned& at) {
+  typedef float __attribute__((ext_vector_type(4))) Vec;
+  typedef const __attribute__((address_space(3))) Vec* LdsPoint;
+  unsigned r = (unsigned)lane & (unsigned)(kChunk3 - 1);
+  asm volatile("" : "+v"(r));                                  // opaque: keeps the 16 offsets from being hoisted out of the ICP loop
+  const unsigned first = tile0 + (unsigned)chunk * (kChunk3 * 16u) + r * 16u;
+#pragma unroll 1
+  for (int h = 0; h < kChunk3; h += 4) {
+    unsigned a4[4];
+    Vec v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { a4[c] = first ^ ((unsigned)(h + c) * 16u); v[c] = *(LdsPoint)(size_t)a4[c]; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d = dist2(a[0], a[1], a[2], v[c].x, v[c].y, v[c].z);
+      const bool lt = d < bd;
+      sec = __builtin_amdgcn_fmed3f(bd, sec, d);
+      at = lt ? a4[c] : at;
+      bd = lt ? d : bd;
+    }
+  }
+}
+
+// LIST: per-lane chunk lists with gathered reads instead of whole-wave chunk evaluation (as in the planar kernel)
+template <int P, bool F64, bool LIST>
 __global__ void __launch_bounds__(kIcpBatchMaxThreads)
 icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
   constexpr int CHUNK = kChunk3;
   constexpr int kAcc = AccLayout<3>::kTotal;
-  extern __shared__ __align__(16) unsigned char smem[];
+  extern __shared__ __align__(kTile3Align) unsigned char smem[];
   float4* tile = reinterpret_cast<float4*>(smem);                                   // sorted targets, padded
   float4* aabb = reinterpret_cast<float4*>(smem + lay.aabb_off);                    // per chunk: lo (x, y, z), hi (x, y, z)
   float4* sh_src = reinterpret_cast<float4*>(smem + lay.src_off);                   // sorted sources (when they fit)
@@ -261,89 +289,156 @@ icp_pruned3_kernel(IcpBatchArgs args, PruneScratch3 sc, PruneLayout lay) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) { wlo[r] = wmin3(wlo[r]); whi[r] = wmax3(whi[r]); }
 
-      // ---- start from last iteration's match (first iteration: the target at the same rank along the curve) ----
-      float best[P], second[P];                              // smallest and second smallest chunk minimum seen so far
-      int bchunk[P];
       bool tie = false;
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int i = base + tid * P + p;
-        best[p] = (i < n) ? INFINITY : -INFINITY;            // lanes without a point never ask for a chunk
-        second[p] = INFINITY;
-        bchunk[p] = 0;
-        if (i < n) {
-          int pv = sh_prev[i];
-          if (pv == 0xffff) pv = (int)(((long long)i * m) / n);
-          const float4 q = tile[pv];
-          // a bound, not yet a candidate: its chunk will beat it strictly (float64-exact mode: by more than the near-tie window)
-          const float ds = dist2(a[p][0], a[p][1], a[p][2], q.x, q.y, q.z);
-          best[p] = F64 ? next_up3(reach(ds) * 1.000001f) : next_up3(ds);
-          bchunk[p] = pv / CHUNK;
-        }
-      }
-
-      // ---- sweep: 64 chunk boxes per ballot against the wave's box and largest bound; survivors get a second look with
-      // every lane's own points and current bounds, then are evaluated with the exact recipe
-      float wb = -INFINITY;
-#pragma unroll
-      for (int p = 0; p < P; ++p) wb = fmaxf(wb, best[p]);
-      wb = wmax3(wb);
-      for (int c0 = 0; c0 < nchunks; c0 += 64) {
-        bool cand = false;
-        if (c0 + lane < nchunks) cand = reach(wb) >= box_dist(wlo, whi, aabb[2 * (c0 + lane)], aabb[2 * (c0 + lane) + 1]);
-        unsigned long long todo = __ballot(cand);
-        while (todo) {
-          const int c = c0 + __builtin_ctzll(todo);
-          todo &= todo - 1;
-          const float4 blo = aabb[2 * c], bhi = aabb[2 * c + 1];
-          bool need_own = false;
-#pragma unroll
-          for (int p = 0; p < P; ++p) need_own |= reach(best[p]) >= box_dist(a[p], a[p], blo, bhi);
-          if (!__any(need_own)) continue;                    // nothing in this chunk can beat or tie any lane
-#pragma unroll
-          for (int p = 0; p < P; ++p) {
-            float mn = INFINITY;
-#pragma unroll
-            for (int k = 0; k < CHUNK; k += 2) {
-              const float4 q0 = tile[c * CHUNK + k], q1 = tile[c * CHUNK + k + 1];
-              mn = fminf(fminf(dist2(a[p][0], a[p][1], a[p][2], q0.x, q0.y, q0.z), dist2(a[p][0], a[p][1], a[p][2], q1.x, q1.y, q1.z)), mn);
-            }
-            const bool lt = mn < best[p];
-            second[p] = __builtin_amdgcn_fmed3f(best[p], second[p], mn);
-            bchunk[p] = lt ? c : bchunk[p];
-            best[p] = lt ? mn : best[p];
-          }
-        }
-      }
       bool near[P];                                          // float64-exact mode: another target within the near-tie window of the winner
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        if constexpr (F64) near[p] = (second[p] <= near_lim(best[p], nt)) && (best[p] < INFINITY);
-        else { near[p] = false; tie |= (second[p] == best[p]) && (best[p] < INFINITY); }
-      }
-
-      // ---- fix-up inside the winning chunk: position of the minimum; equal distances are left to the pass below ----
       int pos[P];
       float bd[P];
-      int rot = lane;
-      asm volatile("" : "+v"(rot));                          // opaque: keeps the 16 rotated offsets from being hoisted out of the ICP loop
+      if constexpr (LIST) {
+        typedef const __attribute__((address_space(3))) float4* LdsTile;
+        const unsigned tile0 = (unsigned)(size_t)(LdsTile)(const void*)tile;
+        // ---- seed: the chunk of last iteration's match (first iteration: of the target at the same rank along the curve), compared
+        // target by target by the lane itself
+        float sec[P];
+        unsigned at[P];
+        int own[P];
 #pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int j0 = bchunk[p] * CHUNK;
-        float sec2 = INFINITY;
-        bd[p] = INFINITY; pos[p] = j0;
-#pragma unroll
-        for (int kk = 0; kk < CHUNK; ++kk) {
-          const int k = (kk + rot) & (CHUNK - 1);
-          const float4 q = tile[j0 + k];
-          const float d = dist2(a[p][0], a[p][1], a[p][2], q.x, q.y, q.z);
-          const bool lt = d < bd[p];
-          sec2 = __builtin_amdgcn_fmed3f(bd[p], sec2, d);
-          pos[p] = lt ? j0 + k : pos[p];
-          bd[p] = lt ? d : bd[p];
+        for (int p = 0; p < P; ++p) {
+          const int i = base + tid * P + p;
+          bd[p] = (i < n) ? INFINITY : -INFINITY;            // lanes without a point never ask for a chunk
+          sec[p] = INFINITY; at[p] = tile0; own[p] = -1;
+          if (i < n) {
+            int pv = sh_prev[i];
+            if (pv == 0xffff) pv = (int)(((long long)i * m) / n);
+            own[p] = pv / CHUNK;
+            prune3_eval_chunk(tile0, own[p], lane, a[p], bd[p], sec[p], at[p]);
+          }
         }
-        if constexpr (F64) { near[p] = (near[p] || (sec2 <= near_lim(bd[p], nt) && bd[p] < INFINITY)) && (base + tid * P + p < n); tie |= near[p]; }
-        else tie |= (sec2 == bd[p]) && (bd[p] < INFINITY);
+        float wb = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < P; ++p) wb = fmaxf(wb, bd[p]);
+        wb = wmax3(wb);
+        // ---- sweep: 64 chunk boxes per ballot against the wave's box and largest bound; each survivor is tested against every
+        // point with its current bound; what a point still needs goes into its 64-bit list, and every lane works through its lists
+        for (int c0 = 0; c0 < nchunks; c0 += 64) {
+          bool cand = false;
+          if (c0 + lane < nchunks) cand = reach(wb) >= box_dist(wlo, whi, aabb[2 * (c0 + lane)], aabb[2 * (c0 + lane) + 1]);
+          unsigned long long todo = __ballot(cand);
+          if (!todo) continue;
+          unsigned long long list[P];
+#pragma unroll
+          for (int p = 0; p < P; ++p) list[p] = 0ull;
+          while (todo) {
+            const int t = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float4 blo = aabb[2 * (c0 + t)], bhi = aabb[2 * (c0 + t) + 1];
+            const unsigned long long bit = 1ull << t;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              // the seed chunk was compared already: a second visit would read as a tie of the point with itself
+              const bool need = reach(bd[p]) >= box_dist(a[p], a[p], blo, bhi) && own[p] != c0 + t;
+              list[p] |= need ? bit : 0ull;
+            }
+          }
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            unsigned long long mk = list[p];
+            while (__any(mk != 0ull)) {
+              if (mk != 0ull) {
+                const int t = __builtin_ctzll(mk);
+                mk &= mk - 1;
+                prune3_eval_chunk(tile0, c0 + t, lane, a[p], bd[p], sec[p], at[p]);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const bool owns = base + tid * P + p < n;
+          pos[p] = (int)((at[p] - tile0) >> 4);
+          if constexpr (F64) { near[p] = owns && bd[p] < INFINITY && sec[p] <= near_lim(bd[p], nt); tie |= near[p]; }
+          else { near[p] = false; tie |= owns && bd[p] < INFINITY && sec[p] == bd[p]; }
+        }
+      } else {
+        // ---- start from last iteration's match (first iteration: the target at the same rank along the curve) ----
+        float best[P], second[P];                              // smallest and second smallest chunk minimum seen so far
+        int bchunk[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int i = base + tid * P + p;
+          best[p] = (i < n) ? INFINITY : -INFINITY;            // lanes without a point never ask for a chunk
+          second[p] = INFINITY;
+          bchunk[p] = 0;
+          if (i < n) {
+            int pv = sh_prev[i];
+            if (pv == 0xffff) pv = (int)(((long long)i * m) / n);
+            const float4 q = tile[pv];
+            // a bound, not yet a candidate: its chunk will beat it strictly (float64-exact mode: by more than the near-tie window)
+            const float ds = dist2(a[p][0], a[p][1], a[p][2], q.x, q.y, q.z);
+            best[p] = F64 ? next_up3(reach(ds) * 1.000001f) : next_up3(ds);
+            bchunk[p] = pv / CHUNK;
+          }
+        }
+
+        // ---- sweep: 64 chunk boxes per ballot against the wave's box and largest bound; survivors get a second look with
+        // every lane's own points and current bounds, then are evaluated with the exact recipe
+        float wb = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < P; ++p) wb = fmaxf(wb, best[p]);
+        wb = wmax3(wb);
+        for (int c0 = 0; c0 < nchunks; c0 += 64) {
+          bool cand = false;
+          if (c0 + lane < nchunks) cand = reach(wb) >= box_dist(wlo, whi, aabb[2 * (c0 + lane)], aabb[2 * (c0 + lane) + 1]);
+          unsigned long long todo = __ballot(cand);
+          while (todo) {
+            const int c = c0 + __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float4 blo = aabb[2 * c], bhi = aabb[2 * c + 1];
+            bool need_own = false;
+#pragma unroll
+            for (int p = 0; p < P; ++p) need_own |= reach(best[p]) >= box_dist(a[p], a[p], blo, bhi);
+            if (!__any(need_own)) continue;                    // nothing in this chunk can beat or tie any lane
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              float mn = INFINITY;
+#pragma unroll
+              for (int k = 0; k < CHUNK; k += 2) {
+                const float4 q0 = tile[c * CHUNK + k], q1 = tile[c * CHUNK + k + 1];
+                mn = fminf(fminf(dist2(a[p][0], a[p][1], a[p][2], q0.x, q0.y, q0.z), dist2(a[p][0], a[p][1], a[p][2], q1.x, q1.y, q1.z)), mn);
+              }
+              const bool lt = mn < best[p];
+              second[p] = __builtin_amdgcn_fmed3f(best[p], second[p], mn);
+              bchunk[p] = lt ? c : bchunk[p];
+              best[p] = lt ? mn : best[p];
+            }
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if constexpr (F64) near[p] = (second[p] <= near_lim(best[p], nt)) && (best[p] < INFINITY);
+          else { near[p] = false; tie |= (second[p] == best[p]) && (best[p] < INFINITY); }
+        }
+
+        // ---- fix-up inside the winning chunk: position of the minimum; equal distances are left to the pass below ----
+        int rot = lane;
+        asm volatile("" : "+v"(rot));                          // opaque: keeps the 16 rotated offsets from being hoisted out of the ICP loop
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int j0 = bchunk[p] * CHUNK;
+          float sec2 = INFINITY;
+          bd[p] = INFINITY; pos[p] = j0;
+#pragma unroll
+          for (int kk = 0; kk < CHUNK; ++kk) {
+            const int k = (kk + rot) & (CHUNK - 1);
+            const float4 q = tile[j0 + k];
+            const float d = dist2(a[p][0], a[p][1], a[p][2], q.x, q.y, q.z);
+            const bool lt = d < bd[p];
+            sec2 = __builtin_amdgcn_fmed3f(bd[p], sec2, d);
+            pos[p] = lt ? j0 + k : pos[p];
+            bd[p] = lt ? d : bd[p];
+          }
+          if constexpr (F64) { near[p] = (near[p] || (sec2 <= near_lim(bd[p], nt) && bd[p] < INFINITY)) && (base + tid * P + p < n); tie |= near[p]; }
+          else tie |= (sec2 == bd[p]) && (bd[p] < INFINITY);
+        }
       }
       // ---- equal minima (duplicate or equidistant points): exhaustive pass, lowest ORIGINAL index wins --
       if constexpr (F64) {
@@ -526,8 +621,14 @@ hipError_t launch_icp_pruned3(IcpBatchArgs a, const PruneScratch3& sc, int S, in
     return hipGetLastError();
   };
   if ((a.src64 == nullptr) != (a.tgt64 == nullptr)) return hipErrorInvalidValue;
-  if (a.src64) return P == 2 ? launch(icp_pruned3_kernel<2, true>) : launch(icp_pruned3_kernel<1, true>);
-  return P == 2 ? launch(icp_pruned3_kernel<2, false>) : launch(icp_pruned3_kernel<1, false>);
+  bool list = true;                                            // LSLAM_ICP_PRUNE_LIST=0: every surviving chunk evaluated by the whole wave (round 2)
+  if (const char* env = getenv("LSLAM_ICP_PRUNE_LIST")) list = atoi(env) != 0;
+  if (list) {
+    if (a.src64) return P == 2 ? launch(icp_pruned3_kernel<2, true, true>) : launch(icp_pruned3_kernel<1, true, true>);
+    return P == 2 ? launch(icp_pruned3_kernel<2, false, true>) : launch(icp_pruned3_kernel<1, false, true>);
+  }
+  if (a.src64) return P == 2 ? launch(icp_pruned3_kernel<2, true, false>) : launch(icp_pruned3_kernel<1, true, false>);
+  return P == 2 ? launch(icp_pruned3_kernel<2, false, false>) : launch(icp_pruned3_kernel<1, false, false>);
 }
 
 }  // namespace lslam

@@ -83,7 +83,7 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
 // 3-D problems (lslam_icp_pruned3d.hip): float4 sorted copies, up to 4096 targets (one 64 KB LDS tile) and 8191 sources
 constexpr int kPrune3MaxTgt = 4096;
 constexpr int kPrune3MaxSrc = 8191;
-constexpr int64_t kAutoPruneBatchPoints3D = 2000;        // automatic choice for 3-D batches (tools/batch3d_probe.py: 1.75 vs 2.39 ms at 2000 points, 1.72 vs 1.43 at 1000)
+constexpr int64_t kAutoPruneBatchPoints3D = 256;         // automatic choice for 3-D batches (tools/batch3d_probe.py, round 3: 0.94 vs 1.07 ms at 250 points, 1.22 vs 1.43 at 1000, 1.19 vs 2.31 at 2000, 1.59 vs 3.55 at 4000; round 2: from 2000)
 struct PruneScratch3 {
   float4* src_sorted; uint16_t* src_index;
   float4* tgt_sorted; uint16_t* tgt_index;

@@ -885,11 +885,14 @@ def test_full_size_dense_3d_identity_search(icp, strategy, monkeypatch, prec):
     np.testing.assert_allclose(T, np.eye(4), atol=1e-12)
 
 
-def test_exact_pruning_3d_gives_the_brute_force_answers(icp, prec):
-    """the 3-D pruned batch kernel (Morton-sorted float4 copies, 16³ grid, chunk boxes in 3-D): identical correspondences and
+@pytest.mark.parametrize("plist", ["1", "0"])
+def test_exact_pruning_3d_gives_the_brute_force_answers(icp, prec, plist, monkeypatch):
+    """(both ways of evaluating the surviving chunks: per-lane lists, the default, and the whole wave)
+    the 3-D pruned batch kernel (Morton-sorted float4 copies, 16³ grid, chunk boxes in 3-D): identical correspondences and
     iteration counts as the all-pairs sweep and as the C oracle's exact recipe — ragged sizes up to the kernel's limits
     (4096 targets, 8191 sources), duplicates far apart in index, a lattice with massive ties, a collapsed target,
     normalised error, a sub-range of a packed buffer"""
+    monkeypatch.setenv("LSLAM_ICP_PRUNE_LIST", plist)
     from lidar_slam_amd.batch import icp_batch
     pack_clouds = prec.pack
     from oracle import c_oracle
