@@ -100,3 +100,19 @@ def test_pack_clouds_keeps_the_precision_it_is_given():
     assert pack_clouds(z64)[0].dtype == np.float64 and pack_clouds(z32)[0].dtype == np.float32
     assert pack_clouds([z32[0], z64[1], z32[2]])[0].dtype == np.float64            # one float64 scan keeps the whole batch exact
     assert pack_clouds(z64, dtype=np.float32)[0].dtype == np.float32
+
+
+def test_tiled_copies_for_multi_start_registration(monkeypatch):
+    """icp_warm_up._tiled: every cloud n_starts times in a row — in the pinned staging buffer when the library provides one,
+    in an ordinary array otherwise; same contents either way (here: no GPU, the fallback)"""
+    from lidar_slam_amd import _lib, icp_warm_up as w
+    def no_staging(slot, count, dtype):
+        raise RuntimeError("no device")
+    monkeypatch.setattr(_lib, "staging_array", no_staging)
+    a = np.arange(12.).reshape(4, 3)
+    b = np.arange(100., 106.).reshape(2, 3)
+    out = w._tiled([a, b], 3, 18, 3, 0)
+    np.testing.assert_array_equal(out, np.vstack([np.tile(a, (3, 1)), np.tile(b, (3, 1))]))
+    assert out.dtype == a.dtype and out.flags["C_CONTIGUOUS"]
+    out32 = w._tiled([a.astype(np.float32)], 2, 8, 3, 1)
+    assert out32.dtype == np.float32 and out32.shape == (8, 3)
