@@ -851,15 +851,22 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // 2. iterate
-  // sources per lane: a wave evaluates every chunk ANY of its 64·P sources needs, so big clouds run with one source per
-  // lane (smaller wave boxes; measured on 4096² problems: 24.9 ms at P = 1, 27.5 at P = 2, 36.3 at P = 4); LiDAR-sized
-  // problems (one pass either way) are 3 % faster with two
-  int P = max_src_n >= 2048 ? 1 : 2;
+  // One source per lane, and about four slabs of 64 sources per wave: a workgroup is then a quarter of the waves a problem
+  // "needs", several problems share a CU (eight LiDAR-sized ones instead of three), and their barriers and one-wave solves —
+  // half of a wave's time in the round-2 geometry — overlap with each other's search; the waves take the slabs from the
+  // counter.  tools/prune_threads.py (10 forced iterations, 4096 problems): 384 points 0.41 ms at 128 lanes against 0.43 at
+  // two points per lane; 768: 0.69 at 256 against 0.86; 1536: 1.35-1.43 at 256-384 against 1.70; 2048: 1.97 at 512 against
+  // 2.44 at 1024; 3072: 3.00 at 768 against 3.09; 4096: 1024 lanes as before.  C3: 0.85 ms against 1.19.
+  int P = 1;
   if (const char* env = getenv("LSLAM_ICP_PRUNE_P")) P = atoi(env);
-  if (P != 1 && P != 2 && P != 4) P = 2;
-  int threads = (int)((((max_src_n + P - 1) / P + 63) / 64) * 64);
+  if (P != 1 && P != 2 && P != 4) P = 1;
+  const int natural = (int)((((max_src_n + P - 1) / P + 63) / 64) * 64);
+  int threads = (int)((max_src_n / (4 * P)) / 64 * 64);       // rounded down: 1081 points -> 256 lanes (0.85 ms on C3; 320: 0.93)
+  if (threads < 128) threads = 128;
+  if (threads > natural) threads = natural;
   if (threads < 64) threads = 64;
-  if (threads > kIcpBatchMaxThreads) threads = kIcpBatchMaxThreads;      // more sources: several passes
+  if (threads > kIcpBatchMaxThreads) threads = kIcpBatchMaxThreads;      // more sources: more slabs per wave
+  if (const char* env = getenv("LSLAM_ICP_PRUNE_THREADS")) { const int t = atoi(env); if (t >= 64 && t <= kIcpBatchMaxThreads && t % 64 == 0) threads = t; }
   const int padded = (int)(((max_tgt_n + kPruneChunk - 1) / kPruneChunk) * kPruneChunk);
   const int nchunks = padded / kPruneChunk;
   PruneLayout lay{};
