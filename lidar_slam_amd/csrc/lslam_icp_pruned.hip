@@ -863,7 +863,7 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   const int natural = (int)((((max_src_n + P - 1) / P + 63) / 64) * 64);
   int threads = (int)((max_src_n / (4 * P)) / 64 * 64);       // rounded down: 1081 points -> 256 lanes (0.85 ms on C3; 320: 0.93)
   if (threads < 128) threads = 128;
-  if (threads > natural) threads = natural;
+  if (S < 256 || threads > natural) threads = natural;          // fewer problems than CUs: every lane the problem can use
   if (threads < 64) threads = 64;
   if (threads > kIcpBatchMaxThreads) threads = kIcpBatchMaxThreads;      // more sources: more slabs per wave
   if (const char* env = getenv("LSLAM_ICP_PRUNE_THREADS")) { const int t = atoi(env); if (t >= 64 && t <= kIcpBatchMaxThreads && t % 64 == 0) threads = t; }

@@ -597,9 +597,20 @@ hipError_t launch_icp_pruned3(IcpBatchArgs a, const PruneScratch3& sc, int S, in
   if (e != hipSuccess) return e;
   int P = 1;
   if (const char* env = getenv("LSLAM_ICP_PRUNE_P")) { const int v = atoi(env); if (v == 1 || v == 2) P = v; }
-  int threads = (int)((((max_src_n + P - 1) / P + 63) / 64) * 64);
+  // Workgroup size: with at least one problem per CU, a quarter of the lanes a problem "needs" (several passes per wave, several
+  // problems per CU whose barriers and solves overlap; as in the planar kernel) — tools/batch3d_probe.py, 10 forced iterations:
+  // 250 points 0.77 ms at 128 lanes against 0.96 at 256; 500: 0.76 at 256 against 1.04 at 512; 1000: 0.81 at 256 against 1.22 at
+  // 1024; 2000: 1.01 at 512 against 1.19; 4000: 1024 lanes (1.59).  Fewer problems than CUs: every lane the problem can use.
+  const int natural = (int)((((max_src_n + P - 1) / P + 63) / 64) * 64);
+  int64_t want = max_src_n / (4 * P);
+  const int64_t half = max_src_n / (2 * P) < 256 ? max_src_n / (2 * P) : 256;
+  if (want < half) want = half;
+  int threads = (int)(((want + 63) / 64) * 64);
+  if (threads < 128) threads = 128;
+  if (S < 256 || threads > natural) threads = natural;
   if (threads < 64) threads = 64;
   if (threads > kIcpBatchMaxThreads) threads = kIcpBatchMaxThreads;      // more sources: several passes
+  if (const char* env = getenv("LSLAM_ICP_PRUNE_THREADS")) { const int t = atoi(env); if (t >= 64 && t <= kIcpBatchMaxThreads && t % 64 == 0) threads = t; }
   const int padded = (int)(((max_tgt_n + kChunk3 - 1) / kChunk3) * kChunk3);
   const int nchunks = padded / kChunk3;
   PruneLayout lay{};
