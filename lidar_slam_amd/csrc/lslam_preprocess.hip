@@ -59,13 +59,20 @@ polar_mask_kernel(const double* __restrict__ ranges, int32_t B, const double* __
 
 // ---- DBSCAN noise mask ---------------------------------------------------------------------------
 // core: uint8 per point (global scratch, so that scans larger than one LDS tile work too)
+// Box pruning (round 3): the points of a tile are grouped 16 at a time in the order they arrive — beam order: 16 consecutive
+// beams are neighbours on a wall — with a float64 box per group in LDS.  A wave (64 consecutive points, compact for the same
+// reason) skips every group whose box is farther than eps from the wave's box, with a margin of 1e-12 relative against the
+// rounding of the distance it compares (a skipped group cannot hold a point the full test would have counted).  On scans in
+// beam order about an eighth of the groups survive; on points in arbitrary order every group does and the result is the same.
+constexpr int kDbGroup = 16;
 template <int PASS>
 __global__ void __launch_bounds__(kPreThreads)
 dbscan_mask_kernel(const double* __restrict__ xy, const int64_t* __restrict__ off, double eps2, int32_t min_samples,
                    uint8_t* __restrict__ core, uint8_t* __restrict__ keep, int32_t* __restrict__ counts, int tile_cap) {
   extern __shared__ __align__(16) unsigned char smem[];
   double2* tile = reinterpret_cast<double2*>(smem);
-  uint8_t* tcore = reinterpret_cast<uint8_t*>(tile + tile_cap);
+  double* gbox = reinterpret_cast<double*>(tile + tile_cap);              // per group {x0, y0, x1, y1}
+  uint8_t* tcore = reinterpret_cast<uint8_t*>(gbox + 4 * (tile_cap / kDbGroup));
   __shared__ int sh[kPreThreads / 64];
   const int k = blockIdx.x;
   const int64_t p0 = off[k];
@@ -76,6 +83,9 @@ dbscan_mask_kernel(const double* __restrict__ xy, const int64_t* __restrict__ of
     const bool live = i < n;
     double xi = 0.0, yi = 0.0;
     if (live) { xi = xy[2 * (p0 + i)]; yi = xy[2 * (p0 + i) + 1]; }
+    // the wave's box (lanes without a point contribute nothing)
+    double wx0 = live ? xi : INFINITY, wy0 = live ? yi : INFINITY, wx1 = live ? xi : -INFINITY, wy1 = live ? yi : -INFINITY;
+    wx0 = wave_min(wx0); wy0 = wave_min(wy0); wx1 = wave_max(wx1); wy1 = wave_max(wy1);
     int cnt = 0;          // PASS 0: neighbours within eps;  PASS 1: core neighbours within eps
     for (int t0 = 0; t0 < n; t0 += tile_cap) {
       const int tn = min(tile_cap, n - t0);
@@ -85,13 +95,30 @@ dbscan_mask_kernel(const double* __restrict__ xy, const int64_t* __restrict__ of
         if (PASS == 1) tcore[j] = core[p0 + t0 + j];
       }
       __syncthreads();
-      if (live) {
-        for (int j = 0; j < tn; ++j) {
-          const double2 q = tile[j];                       // wave-uniform address: LDS broadcast
-          const double dx = xi - q.x, dy = yi - q.y;
-          const double d2 = dx * dx + dy * dy;             // sklearn rdist order, no FMA (-ffp-contract=off)
-          if (PASS == 0) cnt += (d2 <= eps2);
-          else cnt += (d2 <= eps2) & (tcore[j] != 0);
+      const int ngroups = (tn + kDbGroup - 1) / kDbGroup;
+      for (int g = threadIdx.x; g < ngroups; g += kPreThreads) {
+        double x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+        for (int j = g * kDbGroup; j < min(tn, (g + 1) * kDbGroup); ++j) {
+          const double2 q = tile[j];
+          x0 = fmin(x0, q.x); y0 = fmin(y0, q.y); x1 = fmax(x1, q.x); y1 = fmax(y1, q.y);
+        }
+        gbox[4 * g] = x0; gbox[4 * g + 1] = y0; gbox[4 * g + 2] = x1; gbox[4 * g + 3] = y1;
+      }
+      __syncthreads();
+      for (int g = 0; g < ngroups; ++g) {
+        // wave-uniform (the same LDS words and the same wave box in every lane)
+        const double gx = fmax(fmax(gbox[4 * g] - wx1, wx0 - gbox[4 * g + 2]), 0.0);
+        const double gy = fmax(fmax(gbox[4 * g + 1] - wy1, wy0 - gbox[4 * g + 3]), 0.0);
+        if ((gx * gx + gy * gy) * (1.0 - 1e-12) > eps2) continue;
+        if (live) {
+          const int j1 = min(tn, (g + 1) * kDbGroup);
+          for (int j = g * kDbGroup; j < j1; ++j) {
+            const double2 q = tile[j];                       // wave-uniform address: LDS broadcast
+            const double dx = xi - q.x, dy = yi - q.y;
+            const double d2 = dx * dx + dy * dy;             // sklearn rdist order, no FMA (-ffp-contract=off)
+            if (PASS == 0) cnt += (d2 <= eps2);
+            else cnt += (d2 <= eps2) & (tcore[j] != 0);
+          }
         }
       }
     }
@@ -256,7 +283,7 @@ hipError_t launch_dbscan_mask(const double* xy, const int64_t* off, int32_t K, i
   if (K <= 0) return hipSuccess;
   int tile = (int)(max_n < 64 ? 64 : (max_n > 4096 ? 4096 : max_n));
   tile = (tile + 15) & ~15;
-  const size_t smem = (size_t)tile * (sizeof(double2) + 1) + 16;
+  const size_t smem = (size_t)tile * (sizeof(double2) + 1) + (size_t)(tile / 16) * 4 * sizeof(double) + 16;      // points, core flags, one box per 16 points
   const double eps2 = eps * eps;                                   // sklearn: reduced radius = r²
   hipLaunchKernelGGL(dbscan_mask_kernel<0>, dim3(K), dim3(kPreThreads), smem, st, xy, off, eps2, min_samples, core, keep, counts, tile);
   hipLaunchKernelGGL(dbscan_mask_kernel<1>, dim3(K), dim3(kPreThreads), smem, st, xy, off, eps2, min_samples, core, keep, counts, tile);
