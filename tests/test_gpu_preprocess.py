@@ -46,6 +46,23 @@ def test_random_scans_against_oracle_including_empty_and_large():
     exp = P.statistical_outliers_removal(z, 1.0)
     for a, b in zip(got, exp):
         np.testing.assert_array_equal(a, b)
+    # the DBSCAN passes skip groups of 16 consecutive points by their boxes: neighbours at a distance of exactly eps across a group
+    # border (a line of points 0.1 apart), the same line shuffled, a wall-like curve in beam order and shuffled, clusters of
+    # exactly min_samples points — every mask must still equal the full test's
+    line = np.column_stack((np.arange(200) * 0.1, np.zeros(200)))
+    th = np.linspace(-2.3, 2.3, 1081)
+    wall = np.column_stack((4.0 * np.cos(th), 4.0 * np.sin(th))) + rng.normal(0, 0.003, (1081, 2))
+    wall[::97] += 0.5                                                     # isolated returns: noise to be removed
+    blobs = np.vstack([c + rng.normal(0, 0.01, (10, 2)) for c in rng.uniform(-3, 3, (40, 2))])
+    z = [line, line[rng.permutation(200)], wall, wall[rng.permutation(1081)], blobs, blobs[rng.permutation(400)], line * [1.0000001, 1.0]]
+    got = preprocess_lidar(z_ts=z, dbscan=(0.1, 10))
+    exp = P.dbscan_outliers_removal(z, 0.1, 10)
+    for a, b in zip(got, exp):
+        np.testing.assert_array_equal(a, b)
+    got = preprocess_lidar(z_ts=z, dbscan=(0.1, 2))
+    exp = P.dbscan_outliers_removal(z, 0.1, 2)
+    for a, b in zip(got, exp):
+        np.testing.assert_array_equal(a, b)
 
 
 def test_voxel_downsample_matches_reference_and_oracle():
