@@ -54,6 +54,12 @@ int         lslam_set_device(int device);
  * makes the upload one DMA at PCIe speed (no reference counterpart: the reference never leaves the host). */
 int         lslam_host_staging(int slot, size_t bytes, void **out_ptr);
 
+/* Device and pinned memory the library keeps per calling thread between calls (scratch arena, the staging buffers above,
+ * the spatially ordered copies of the pruned batch kernels, the workspaces of the single-pair paths, the thread's stream):
+ * they only grow, each growth behind a hipDeviceSynchronize().  A long-lived service returns them with this call (it waits
+ * for the device, frees, and the thread's next call allocates afresh).  No reference counterpart. */
+int         lslam_release_thread_resources(void);
+
 /* Measurement aid (no reference counterpart): the float32 VALU issue rate this device sustains
  * under an all-VALU load, in lane-operations per second (≈ 10 ms of v_fma_f32 on every SIMD). */
 int         lslam_valu_probe(int device, double *out_lane_ops_per_s);
@@ -171,6 +177,15 @@ int lslam_icp_large_dev(const float *d_src, int64_t n, const float *d_tgt, int64
                         uint32_t flags, int32_t poll_every,
                         double *out_T, double *out_err, int32_t *out_iters,
                         int32_t *d_out_corr, void *stream);
+
+/* LiDAR-sized single pairs (below 8192 source points, target within one LDS tile) run the WHOLE iteration loop inside one
+ * launch of co-resident workgroups that hand their partial moments to each other through memory.  That needs every
+ * workgroup on a CU of its own at the same time: the library takes this path only when the grid is at most half of the
+ * device's CUs (LSLAM_ICP_COOP_MAX_CUS in the environment caps the CU count assumed; LSLAM_ICP_COOP=0 disables the path), and
+ * when a workgroup still waits longer than 50 ms for the others (CUs held by other streams or processes) the launch drains,
+ * and the SAME call runs the problem again from init_T on the launch-per-iteration path — same result, never an error.
+ * lslam_icp_coop_fallbacks(): how many calls of this thread took that detour. */
+int lslam_icp_coop_fallbacks(void);
 
 /* float64-exact mode of the two entry points above (see lslam_icp_batch_f64): the float64 clouds decide near
  * ties and feed the moments.  Both search strategies are available (the pruned search adds one refine launch per

@@ -8,5 +8,6 @@ hand-written HIP kernels through the C ABI of ``include/lslam.h`` (ctypes).  The
 fallback: without ``liblslam_hip.so`` and a HIP device every compute call raises.
 """
 from ._lib import LslamError, device_count, lib  # noqa: F401
+from .batch import release_thread_resources  # noqa: F401
 
 __version__ = "0.1.0"

@@ -60,6 +60,14 @@ for _name in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "e
 _STAGED_POINTS = {}          # (slot, dim, dtype) -> points the thread's pinned staging slot is known to hold
 
 
+def release_thread_resources():
+    """Hands the calling thread's library-owned device and pinned memory back (``lslam_release_thread_resources``): scratch
+    arena, pinned staging buffers, the ordered copies of the pruned kernels, single-pair workspaces.  The next call
+    allocates again.  Arrays previously returned by the staging helpers must not be used afterwards."""
+    _STAGED_POINTS.clear()
+    check(lib().lslam_release_thread_resources())
+
+
 class StagedClouds(np.ndarray):
     """a packed cloud array living in the library's pinned staging buffer; ``.checked`` = every coordinate was seen finite
     while packing (the library then skips its own pass: LSLAM_ICP_INPUT_CHECKED)"""

@@ -25,6 +25,8 @@ int fail(int code, const char* fmt, ...) {
 }
 void clear_error() { g_err[0] = 0; }
 
+static thread_local int g_coop_fallbacks = 0;     // calls of this thread whose co-resident launch timed out and was re-run launch by launch
+
 // ---- scratch arena --------------------------------------------------------------------------------
 int Arena::reserve(int device, size_t bytes) {
   used_ = 0;
@@ -36,6 +38,10 @@ int Arena::reserve(int device, size_t bytes) {
   device_ = device;
   return LSLAM_OK;
 }
+void Arena::release() {
+  if (base_) (void)hipFree(base_);
+  base_ = nullptr; cap_ = 0; used_ = 0; device_ = -1;
+}
 void* Arena::carve(size_t bytes) {
   void* p = static_cast<char*>(base_) + used_;
   used_ += align(bytes);
@@ -45,12 +51,20 @@ Arena& thread_arena() {
   static thread_local Arena a;
   return a;
 }
+static thread_local hipStream_t g_thread_stream = nullptr;
+static thread_local int g_thread_stream_dev = -1;
 int thread_stream(hipStream_t* out) {
-  static thread_local hipStream_t s = nullptr;
-  static thread_local int dev = -1;
+  hipStream_t& s = g_thread_stream;
+  int& dev = g_thread_stream_dev;
   int cur = 0;
   LSLAM_HIP_TRY(hipGetDevice(&cur));
   if (!s || dev != cur) {
+    if (s) {                                                 // the thread moved to another device: the old stream is drained and destroyed
+      int back = cur;
+      if (hipSetDevice(dev) == hipSuccess) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+      (void)hipSetDevice(back);
+      s = nullptr;
+    }
     LSLAM_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     dev = cur;
   }
@@ -136,6 +150,105 @@ struct WsFence {
 };
 static WsFence& ws_fence() { static thread_local WsFence f; return f; }
 
+// Spatially ordered copies of a pruned batch (pair-local slots of S x max points: the caller's offsets live on the device and may
+// start anywhere), kept by the calling thread and reused by its next call; grown behind a hipDeviceSynchronize().
+struct PruneHolder {
+  PruneScratch sc{};
+  size_t cap_src = 0, cap_tgt = 0, cap_src64 = 0, cap_tgt64 = 0;
+  int device = -1;
+  void release() {
+    if (sc.src_sorted) (void)hipFree(sc.src_sorted);
+    if (sc.src_index) (void)hipFree(sc.src_index);
+    if (sc.tgt_sorted) (void)hipFree(sc.tgt_sorted);
+    if (sc.tgt_index) (void)hipFree(sc.tgt_index);
+    if (sc.src64_sorted) (void)hipFree(sc.src64_sorted);
+    if (sc.tgt64_sorted) (void)hipFree(sc.tgt64_sorted);
+    if (sc.queue) (void)hipFree(sc.queue);
+    sc = PruneScratch{}; cap_src = cap_tgt = cap_src64 = cap_tgt64 = 0; device = -1;
+  }
+  int ensure(int32_t S, int64_t max_src_n, int64_t max_tgt_n, bool f64) {
+    int dev = 0;
+    LSLAM_HIP_TRY(hipGetDevice(&dev));
+    const size_t need_src = (size_t)S * (size_t)max_src_n, need_tgt = (size_t)S * (size_t)max_tgt_n;   // one slot per problem
+    if (dev != device || need_src > cap_src || need_tgt > cap_tgt) {
+      LSLAM_HIP_TRY(hipDeviceSynchronize());                 // earlier launches may still read the old buffers
+      release();
+      device = dev;
+      LSLAM_HIP_TRY(hipMalloc(&sc.queue, 256));
+      LSLAM_HIP_TRY(hipMalloc(&sc.src_sorted, sizeof(float2) * need_src));
+      LSLAM_HIP_TRY(hipMalloc(&sc.src_index, sizeof(uint16_t) * need_src));
+      LSLAM_HIP_TRY(hipMalloc(&sc.tgt_sorted, sizeof(float2) * need_tgt));
+      LSLAM_HIP_TRY(hipMalloc(&sc.tgt_index, sizeof(uint16_t) * need_tgt));
+      cap_src = need_src; cap_tgt = need_tgt;
+    }
+    // float64-exact mode: the float64 clouds in the sorted order as well (allocated on first use, sized like the others)
+    if (f64 && (need_src > cap_src64 || need_tgt > cap_tgt64 || !sc.src64_sorted)) {
+      LSLAM_HIP_TRY(hipDeviceSynchronize());
+      if (sc.src64_sorted) (void)hipFree(sc.src64_sorted);
+      if (sc.tgt64_sorted) (void)hipFree(sc.tgt64_sorted);
+      sc.src64_sorted = nullptr; sc.tgt64_sorted = nullptr; cap_src64 = cap_tgt64 = 0;
+      LSLAM_HIP_TRY(hipMalloc(&sc.src64_sorted, sizeof(double2) * need_src));
+      LSLAM_HIP_TRY(hipMalloc(&sc.tgt64_sorted, sizeof(double2) * need_tgt));
+      cap_src64 = need_src; cap_tgt64 = need_tgt;
+    }
+    sc.src_stride = max_src_n; sc.tgt_stride = max_tgt_n;
+    return LSLAM_OK;
+  }
+};
+static PruneHolder& prune_holder() { static thread_local PruneHolder h; return h; }
+
+struct Prune3Holder {
+  PruneScratch3 sc{};
+  size_t cap_src = 0, cap_tgt = 0, cap_src64 = 0, cap_tgt64 = 0;
+  int device = -1;
+  void release() {
+    if (sc.src_sorted) (void)hipFree(sc.src_sorted);
+    if (sc.src_index) (void)hipFree(sc.src_index);
+    if (sc.tgt_sorted) (void)hipFree(sc.tgt_sorted);
+    if (sc.tgt_index) (void)hipFree(sc.tgt_index);
+    if (sc.src64_sorted) (void)hipFree(sc.src64_sorted);
+    if (sc.tgt64_sorted) (void)hipFree(sc.tgt64_sorted);
+    sc = PruneScratch3{}; cap_src = cap_tgt = cap_src64 = cap_tgt64 = 0; device = -1;
+  }
+  int ensure(int32_t S, int64_t max_src_n, int64_t max_tgt_n, bool f64) {
+    int dev = 0;
+    LSLAM_HIP_TRY(hipGetDevice(&dev));
+    const size_t need_src = (size_t)S * (size_t)max_src_n, need_tgt = (size_t)S * (size_t)max_tgt_n;
+    if (dev != device || need_src > cap_src || need_tgt > cap_tgt) {
+      LSLAM_HIP_TRY(hipDeviceSynchronize());
+      release();
+      device = dev;
+      LSLAM_HIP_TRY(hipMalloc(&sc.src_sorted, sizeof(float4) * need_src));
+      LSLAM_HIP_TRY(hipMalloc(&sc.src_index, sizeof(uint16_t) * need_src));
+      LSLAM_HIP_TRY(hipMalloc(&sc.tgt_sorted, sizeof(float4) * need_tgt));
+      LSLAM_HIP_TRY(hipMalloc(&sc.tgt_index, sizeof(uint16_t) * need_tgt));
+      cap_src = need_src; cap_tgt = need_tgt;
+    }
+    if (f64 && (need_src > cap_src64 || need_tgt > cap_tgt64 || !sc.src64_sorted)) {
+      LSLAM_HIP_TRY(hipDeviceSynchronize());
+      if (sc.src64_sorted) (void)hipFree(sc.src64_sorted);
+      if (sc.tgt64_sorted) (void)hipFree(sc.tgt64_sorted);
+      sc.src64_sorted = nullptr; sc.tgt64_sorted = nullptr; cap_src64 = cap_tgt64 = 0;
+      LSLAM_HIP_TRY(hipMalloc(&sc.src64_sorted, sizeof(double) * 3 * need_src));
+      LSLAM_HIP_TRY(hipMalloc(&sc.tgt64_sorted, sizeof(double) * 3 * need_tgt));
+      cap_src64 = need_src; cap_tgt64 = need_tgt;
+    }
+    sc.src_stride = max_src_n; sc.tgt_stride = max_tgt_n;
+    return LSLAM_OK;
+  }
+};
+static Prune3Holder& prune3_holder() { static thread_local Prune3Holder h; return h; }
+
+// pinned host staging buffers of the calling thread (lslam_host_staging)
+struct StagingHolder {
+  void* buf[2] = {nullptr, nullptr};
+  size_t cap[2] = {0, 0};
+  void release() {
+    for (int k = 0; k < 2; ++k) { if (buf[k]) (void)hipHostFree(buf[k]); buf[k] = nullptr; cap[k] = 0; }
+  }
+};
+static StagingHolder& staging_holder() { static thread_local StagingHolder h; return h; }
+
 }  // namespace lslam
 
 using namespace lslam;
@@ -161,8 +274,9 @@ int lslam_set_device(int device) {
 int lslam_host_staging(int slot, size_t bytes, void** out_ptr) {
   clear_error();
   if (!out_ptr || slot < 0 || slot > 1) return fail(LSLAM_ERR_BAD_ARG, "slot must be 0 or 1 and out_ptr non-null");
-  static thread_local void* buf[2] = {nullptr, nullptr};
-  static thread_local size_t cap[2] = {0, 0};
+  StagingHolder& sh = staging_holder();
+  void** buf = sh.buf;
+  size_t* cap = sh.cap;
   if (bytes > cap[slot]) {
     if (buf[slot]) { LSLAM_HIP_TRY(hipDeviceSynchronize()); (void)hipHostFree(buf[slot]); }
     buf[slot] = nullptr; cap[slot] = 0;
@@ -220,77 +334,17 @@ static int icp_batch_dev_impl(const float* d_src, const double* d_src64, const i
   const int pruned = batch_prune_choice(dim, flags, max_src_n, max_tgt_n);
   const bool prune = pruned != 0;
   if (prune && dim == 3 && icp_pruned3_supported(max_src_n, max_tgt_n)) {
-    static thread_local PruneScratch3 sc3{};
-    static thread_local size_t cap3_src = 0, cap3_tgt = 0;
-    static thread_local int sc3_dev = -1;
-    int dev = 0;
-    LSLAM_HIP_TRY(hipGetDevice(&dev));
-    const size_t need_src = (size_t)S * (size_t)max_src_n, need_tgt = (size_t)S * (size_t)max_tgt_n;   // one slot per problem
-    if (dev != sc3_dev || need_src > cap3_src || need_tgt > cap3_tgt) {
-      LSLAM_HIP_TRY(hipDeviceSynchronize());                 // earlier launches may still read the old buffers
-      if (sc3.src_sorted) (void)hipFree(sc3.src_sorted);
-      if (sc3.src_index) (void)hipFree(sc3.src_index);
-      if (sc3.tgt_sorted) (void)hipFree(sc3.tgt_sorted);
-      if (sc3.tgt_index) (void)hipFree(sc3.tgt_index);
-      if (sc3.src64_sorted) (void)hipFree(sc3.src64_sorted);
-      if (sc3.tgt64_sorted) (void)hipFree(sc3.tgt64_sorted);
-      sc3 = PruneScratch3{}; cap3_src = cap3_tgt = 0; sc3_dev = dev;
-      LSLAM_HIP_TRY(hipMalloc(&sc3.src_sorted, sizeof(float4) * need_src));
-      LSLAM_HIP_TRY(hipMalloc(&sc3.src_index, sizeof(uint16_t) * need_src));
-      LSLAM_HIP_TRY(hipMalloc(&sc3.tgt_sorted, sizeof(float4) * need_tgt));
-      LSLAM_HIP_TRY(hipMalloc(&sc3.tgt_index, sizeof(uint16_t) * need_tgt));
-      cap3_src = need_src; cap3_tgt = need_tgt;
-    }
-    // float64-exact mode: the float64 clouds in sorted order as well (allocated on first use, sized like the others)
-    static thread_local size_t cap3_src64 = 0, cap3_tgt64 = 0;
-    if (d_src64 && (dev != sc3_dev || need_src > cap3_src64 || need_tgt > cap3_tgt64 || !sc3.src64_sorted)) {
-      LSLAM_HIP_TRY(hipDeviceSynchronize());
-      if (sc3.src64_sorted) (void)hipFree(sc3.src64_sorted);
-      if (sc3.tgt64_sorted) (void)hipFree(sc3.tgt64_sorted);
-      sc3.src64_sorted = nullptr; sc3.tgt64_sorted = nullptr; cap3_src64 = cap3_tgt64 = 0;
-      LSLAM_HIP_TRY(hipMalloc(&sc3.src64_sorted, sizeof(double) * 3 * need_src));
-      LSLAM_HIP_TRY(hipMalloc(&sc3.tgt64_sorted, sizeof(double) * 3 * need_tgt));
-      cap3_src64 = need_src; cap3_tgt64 = need_tgt;
-    }
-    sc3.src_stride = max_src_n; sc3.tgt_stride = max_tgt_n;
-    LSLAM_HIP_TRY(launch_icp_pruned3(a, sc3, S, max_src_n, max_tgt_n, static_cast<hipStream_t>(stream)));
+    Prune3Holder& h = prune3_holder();
+    int rc = h.ensure(S, max_src_n, max_tgt_n, d_src64 != nullptr);
+    if (rc != LSLAM_OK) return rc;
+    LSLAM_HIP_TRY(launch_icp_pruned3(a, h.sc, S, max_src_n, max_tgt_n, static_cast<hipStream_t>(stream)));
     return LSLAM_OK;
   }
   if (prune && dim == 2 && icp_pruned_supported(dim, max_src_n, max_tgt_n)) {
-    // sorted copies in pair-local slots of S x max points (the offsets live on the device and may start anywhere)
-    static thread_local PruneScratch sc{};
-    static thread_local size_t cap_src = 0, cap_tgt = 0;
-    static thread_local int sc_dev = -1;
-    int dev = 0;
-    LSLAM_HIP_TRY(hipGetDevice(&dev));
-    const size_t need_src = (size_t)S * (size_t)max_src_n, need_tgt = (size_t)S * (size_t)max_tgt_n;   // one slot per problem
-    if (dev != sc_dev || need_src > cap_src || need_tgt > cap_tgt) {
-      LSLAM_HIP_TRY(hipDeviceSynchronize());                 // earlier launches may still read the old buffers
-      if (sc.src_sorted) (void)hipFree(sc.src_sorted);
-      if (sc.src_index) (void)hipFree(sc.src_index);
-      if (sc.tgt_sorted) (void)hipFree(sc.tgt_sorted);
-      if (sc.tgt_index) (void)hipFree(sc.tgt_index);
-      if (sc.src64_sorted) (void)hipFree(sc.src64_sorted);
-      if (sc.tgt64_sorted) (void)hipFree(sc.tgt64_sorted);
-      sc = PruneScratch{}; cap_src = cap_tgt = 0; sc_dev = dev;
-      LSLAM_HIP_TRY(hipMalloc(&sc.src_sorted, sizeof(float2) * need_src));
-      LSLAM_HIP_TRY(hipMalloc(&sc.src_index, sizeof(uint16_t) * need_src));
-      LSLAM_HIP_TRY(hipMalloc(&sc.tgt_sorted, sizeof(float2) * need_tgt));
-      LSLAM_HIP_TRY(hipMalloc(&sc.tgt_index, sizeof(uint16_t) * need_tgt));
-      cap_src = need_src; cap_tgt = need_tgt;
-    }
-    static thread_local size_t cap_src64 = 0, cap_tgt64 = 0;
-    if (d_src64 && (need_src > cap_src64 || need_tgt > cap_tgt64 || !sc.src64_sorted)) {
-      LSLAM_HIP_TRY(hipDeviceSynchronize());
-      if (sc.src64_sorted) (void)hipFree(sc.src64_sorted);
-      if (sc.tgt64_sorted) (void)hipFree(sc.tgt64_sorted);
-      sc.src64_sorted = nullptr; sc.tgt64_sorted = nullptr; cap_src64 = cap_tgt64 = 0;
-      LSLAM_HIP_TRY(hipMalloc(&sc.src64_sorted, sizeof(double2) * need_src));
-      LSLAM_HIP_TRY(hipMalloc(&sc.tgt64_sorted, sizeof(double2) * need_tgt));
-      cap_src64 = need_src; cap_tgt64 = need_tgt;
-    }
-    sc.src_stride = max_src_n; sc.tgt_stride = max_tgt_n;
-    LSLAM_HIP_TRY(launch_icp_pruned(a, sc, S, max_src_n, max_tgt_n, static_cast<hipStream_t>(stream)));
+    PruneHolder& h = prune_holder();
+    int rc = h.ensure(S, max_src_n, max_tgt_n, d_src64 != nullptr);
+    if (rc != LSLAM_OK) return rc;
+    LSLAM_HIP_TRY(launch_icp_pruned(a, h.sc, S, max_src_n, max_tgt_n, static_cast<hipStream_t>(stream)));
     return LSLAM_OK;
   }
   LSLAM_HIP_TRY(launch_icp_batch(a, dim, S, max_src_n, max_tgt_n, tuning_from_env(), static_cast<hipStream_t>(stream)));
@@ -592,6 +646,7 @@ struct LpHolder {
   }
 };
 LpHolder& lp_holder() { static thread_local LpHolder h; return h; }
+void lp_release() { LpHolder& h = lp_holder(); if (h.block) (void)hipFree(h.block); h.block = nullptr; h.cap = 0; h.device = -1; }
 }  // namespace
 }  // extern "C++"
 
@@ -642,11 +697,17 @@ static int icp_large_dev_impl(const float* d_src, const double* d_src64, int64_t
               ws.h_back[0]->stop.executed, pr[0] * 0.01, pr[1] * 0.01, pr[2] * 0.01, pr[3] * 0.01, pr[4] * 0.01, pr[5] * 0.01, pr[6] * 0.01, pr[7] * 0.01);
     }
 #endif
-    if (ws.h_failed[0]) return fail(LSLAM_ERR_HIP, "co-resident ICP launch: a workgroup timed out waiting for the others");
-    memcpy(out_T, ws.h_back[0]->T, sizeof(double) * 16);
-    *out_err = ws.h_back[0]->err;
-    *out_iters = ws.h_back[0]->stop.executed;
-    return LSLAM_OK;
+    if (!ws.h_failed[0]) {
+      memcpy(out_T, ws.h_back[0]->T, sizeof(double) * 16);
+      *out_err = ws.h_back[0]->err;
+      *out_iters = ws.h_back[0]->stop.executed;
+      return LSLAM_OK;
+    }
+    // A workgroup gave up waiting for the others (they never all became resident: the CUs were held by other work).  The
+    // launch has drained; the problem is run again from init_T on the launch-per-iteration path below, which needs no
+    // co-residency — same result, more launches.
+    g_coop_fallbacks += 1;
+    if (getenv("LSLAM_DEBUG")) fprintf(stderr, "[lslam] co-resident ICP launch timed out waiting for its workgroups: taking the launch-per-iteration path\n");
   }
   if (f64) {                                                // the near ties are decided by the moments kernel (all pairs) / a refine launch (pruned)
     if ((rc = ws.ensure_sec(prune ? 1 : n * geo.splits)) != LSLAM_OK) return rc;
@@ -1588,6 +1649,33 @@ int lslam_ogm_binarize(void* handle, uint8_t* out) {
   LSLAM_HIP_TRY(launch_ogm_binarize(o->g, o->d_bin, o->stream));
   LSLAM_HIP_TRY(hipMemcpyAsync(out, o->d_bin, (size_t)o->g.width * o->g.height, hipMemcpyDeviceToHost, o->stream));
   LSLAM_HIP_TRY(hipStreamSynchronize(o->stream));
+  return LSLAM_OK;
+}
+
+
+/* how many calls of this thread had their co-resident one-launch ICP (LiDAR-sized single pairs) time out waiting for its
+ * workgroups and were re-run on the launch-per-iteration path — 0 on an otherwise idle device */
+int lslam_icp_coop_fallbacks(void) { return g_coop_fallbacks; }
+
+/* Returns what the calling thread's earlier calls left allocated on the current device side: the scratch arena, the pinned
+ * staging buffers, the spatially ordered copies of the pruned batch kernels, the workspaces of the single-pair paths and the
+ * thread's stream.  Waits for the device first; the next call simply allocates again. */
+int lslam_release_thread_resources(void) {
+  clear_error();
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return LSLAM_OK;      // nothing was ever allocated
+  LSLAM_HIP_TRY(hipDeviceSynchronize());
+  thread_arena().release();
+  staging_holder().release();
+  prune_holder().release();
+  prune3_holder().release();
+  large_ws().release();
+  large_ws().device = -1;
+  lp_release();
+  if (g_thread_stream) { (void)hipStreamDestroy(g_thread_stream); g_thread_stream = nullptr; g_thread_stream_dev = -1; }
+  WsFence& f = ws_fence();
+  if (f.ev) { (void)hipEventDestroy(f.ev); f.ev = nullptr; }
+  f.armed = false; f.device = -1; f.last = nullptr;
   return LSLAM_OK;
 }
 

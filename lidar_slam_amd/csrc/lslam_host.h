@@ -27,6 +27,7 @@ class Arena {
  public:
   int reserve(int device, size_t bytes);      // LSLAM_OK or error
   void* carve(size_t bytes);
+  void release();                             // frees the block (the caller has synchronised the device)
   static size_t align(size_t b) { return (b + 255) & ~(size_t)255; }
 
  private:

@@ -42,7 +42,7 @@ template <> struct CoopChunk<3> { static constexpr int value = 8; };
 
 // wall clock in 100 MHz ticks (s_memrealtime): bounds every spin so that the grid always drains
 __device__ __forceinline__ unsigned long long coop_now() { return wall_clock64(); }
-constexpr unsigned long long kCoopTimeoutTicks = 400000000ull;     // 4 s
+constexpr unsigned long long kCoopTimeoutTicksDefault = 5000000ull;      // 50 ms of the 100 MHz wall clock per hand-off (a healthy one takes microseconds); the host then takes the launch-per-iteration path
 
 // values of a workgroup's row: Σp, Σq, Σpqᵀ, Σ‖p−q‖² (the pair count is n for everybody) [+ joint box when normalising]
 template <int DIM> struct CoopRow {
@@ -424,7 +424,7 @@ icp_coop_kernel(CoopArgs a) {
           ok &= here;
         }
         if (__all(ok)) break;
-        if (coop_now() - t0 > kCoopTimeoutTicks) { failed = true; break; }
+        if (coop_now() - t0 > a.timeout_ticks) { failed = true; break; }
         __builtin_amdgcn_s_sleep(1);
       }
       failed = __any(failed);
@@ -528,9 +528,30 @@ static int64_t coop_max_targets(int dim, bool f64) {
   return dim == 2 ? 4096 : 2048;
 }
 
+int icp_coop_sub(int64_t n);
+
+// CUs the co-resident launch may count on: every workgroup needs a CU of its own (≥ 40 KB of LDS and 16 waves each), so the
+// grid must not exceed the device's CU count — a partitioned device (CPX: 32 CUs) or a smaller part takes the launch-per-
+// iteration path instead.  LSLAM_ICP_COOP_MAX_CUS caps the figure (tests; a service that shares the device).
+static int coop_cus() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus = n;
+  }
+  int c = cus;
+  if (const char* e = getenv("LSLAM_ICP_COOP_MAX_CUS")) { const int v = atoi(e); if (v >= 0 && v < c) c = v; }
+  return c;
+}
+
 bool icp_coop_supported(int dim, int64_t n, int64_t m, bool f64) {
   if (const char* e = getenv("LSLAM_ICP_COOP")) if (atoi(e) == 0) return false;
-  return n >= 1 && n < 8192 && m >= 1 && m <= coop_max_targets(dim, f64);
+  if (!(n >= 1 && n < 8192 && m >= 1 && m <= coop_max_targets(dim, f64))) return false;
+  const int spw = 64 / icp_coop_sub(n);
+  const int64_t G = (n + spw - 1) / spw;
+  // half of the CUs at most: the workgroups must all become resident while other streams of the process may hold CUs too
+  return G * 2 <= (int64_t)coop_cus();
 }
 
 int icp_coop_sub(int64_t n) {
@@ -558,6 +579,8 @@ hipError_t launch_icp_coop(CoopArgs a, int dim, hipStream_t stream) {
   a.tile64_bytes = f64 ? (uint32_t)(((size_t)a.m * dim * 8 + 15) & ~(size_t)15) : 0u;
   a.gran_bytes = (uint32_t)icp_coop_gran_bytes(dim, a.n);
   a.box_bytes = (uint32_t)((size_t)(padded / CH) * (dim == 2 ? 16 : 32));
+  a.timeout_ticks = kCoopTimeoutTicksDefault;
+  if (const char* e = getenv("LSLAM_ICP_COOP_TIMEOUT_US")) { const long long us = atoll(e); if (us >= 0) a.timeout_ticks = (unsigned long long)us * 100ull; }
   const size_t slots = (size_t)kCoopWaves * 64;                  // NS·SPW
   const size_t smem = a.tile_bytes + a.tile64_bytes + a.box_bytes + 64 * 4 + slots * (8 + 4) + (32 * 65 + 64 * 8) * 8 + 64 * (8 + 4) + (size_t)G * kVals * 2 * 4 +
                       17 * 8 + sizeof(StopState) + 32;

@@ -22,15 +22,9 @@
 
 #include "lslam_device.h"
 #include "lslam_kernels.h"
+#include "lslam_prune_common.h"
 
 namespace lslam {
-
-#ifndef LSLAM_PRUNE_CHUNK
-#define LSLAM_PRUNE_CHUNK 16
-#endif
-constexpr int kPruneChunk = LSLAM_PRUNE_CHUNK;   // targets per box (8 was measured: see DESIGN §3.1b)
-constexpr int kSortThreads = 256;
-constexpr float kPruneSafety = 0.99999f;
 
 __device__ __forceinline__ unsigned morton5(unsigned x, unsigned y) {      // interleave two 5-bit coordinates
   unsigned r = 0;
@@ -52,22 +46,6 @@ __device__ __forceinline__ unsigned hilbert_index(unsigned x, unsigned y, unsign
     }
   }
   return d;
-}
-
-// the next float above a non-negative finite float (or +inf)
-__device__ __forceinline__ float next_up(float v) {
-  return v < INFINITY ? __uint_as_float(__float_as_uint(v) + 1u) : v;
-}
-
-__device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
 }
 
 // ascending bitonic sort of `len` (power of two) uint32 keys in LDS
@@ -274,34 +252,6 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, 
     sc.src_sorted[ss + i] = pts[o];
     sc.src_index[ss + i] = (uint16_t)o;
     if (a.src64) sc.src64_sorted[ss + i] = reinterpret_cast<const double2*>(a.src64)[s0 + o];
-  }
-}
-
-// One chunk of 16 sorted targets against ONE point of this lane, the chunk chosen by the lane (a gather): every target is
-// compared, (bd, sec) = the smallest and second smallest distance over everything evaluated for the point so far, at = the LDS
-// address of the nearest target.  Lane l visits target (k XOR l) at step k: chunks start on the same banks, and the XOR
-// costs one instruction per address (the arithmetic is done on the 32-bit LDS address: see lslam_icp_batch.hip, exact_chunk).
-constexpr int kPruneTileAlign = kPruneChunk * 8;
-__device__ __forceinline__ void prune_eval_chunk(unsigned tile0, int chunk, int lane, float x, float y, float& bd, float& sec, unsigned& at) {
-  typedef float __attribute__((ext_vector_type(2))) Vec;
-  typedef const __attribute__((address_space(3))) Vec* LdsPoint;
-  unsigned r = (unsigned)lane & (unsigned)(kPruneChunk - 1);
-  asm volatile("" : "+v"(r));                                  // opaque: keeps the 16 offsets from being hoisted out of the ICP loop (and spilled)
-  const unsigned first = tile0 + (unsigned)chunk * (kPruneChunk * 8u) + r * 8u;
-#pragma unroll 1
-  for (int h = 0; h < kPruneChunk; h += 8) {
-    unsigned a8[8];
-    Vec v[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { a8[c] = first ^ ((unsigned)(h + c) * 8u); v[c] = *(LdsPoint)(size_t)a8[c]; }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float d = dist2(x, y, v[c].x, v[c].y);
-      const bool lt = d < bd;
-      sec = __builtin_amdgcn_fmed3f(bd, sec, d);
-      at = lt ? a8[c] : at;
-      bd = lt ? d : bd;
-    }
   }
 }
 
@@ -850,7 +800,15 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   hipLaunchKernelGGL(icp_sort_kernel, dim3(S), dim3(kSortThreads), sort_lds, stream, a, sc, len, keep, curve, cap, cur_words);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  // 2. iterate
+  // 2. iterate.  The task-queue kernel (lslam_icp_queue.hip: problems in LDS slots, waves draw tasks, no barriers) where a CU
+  // holds at least three problems — LiDAR-sized float32 clouds: the C3 sequence 0.74 ms against 0.87 — and one problem per
+  // workgroup (below) elsewhere: with one or two problems per CU the queue has nothing to fill a finishing problem's gap with (C4:
+  // 16.6 against 16.0 ms; float64-exact clouds take twice the LDS: C3 0.99 against 0.96 ms).  LSLAM_ICP_PRUNE_QUEUE=1 / 0 forces either.
+  {
+    bool queue = a.src64 == nullptr && max_src_n <= 2048 && max_tgt_n <= 2048;
+    if (const char* env = getenv("LSLAM_ICP_PRUNE_QUEUE")) queue = atoi(env) != 0;
+    if (queue && sc.queue) return launch_icp_queue(a, sc, S, max_src_n, max_tgt_n, stream);
+  }
   // One source per lane, and about four slabs of 64 sources per wave: a workgroup is then a quarter of the waves a problem
   // "needs", several problems share a CU (eight LiDAR-sized ones instead of three), and their barriers and one-wave solves —
   // half of a wave's time in the round-2 geometry — overlap with each other's search; the waves take the slabs from the

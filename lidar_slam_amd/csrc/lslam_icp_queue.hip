@@ -1,0 +1,726 @@
+// lslam_icp_queue.hip — the batched planar ICP with exact chunk pruning as a TASK QUEUE (the default from 256 points per cloud).
+//
+// Same operator, same search, same results as icp_pruned_kernel (lslam_icp_pruned.hip; modules/icp.py:123-189, the per-pair
+// loop of modules/localization.py:115-124) — what changes is who waits for whom.  There, a problem is a workgroup: every
+// iteration its waves meet at two barriers around a one-wave solve.  Here a workgroup is a pool of waves that stays on its CU
+// for the whole launch and keeps Q problems ("slots") in LDS.  The unit of work is a TASK = G consecutive slabs of 64 sorted
+// sources of one problem in its current iteration:
+//   * a wave takes the next task of any slot that has one (an LDS counter per slot), searches its sources, accumulates their
+//     float64 moments and leaves one row of partial sums per task;
+//   * the wave that completes a slot's LAST task of the iteration sums the rows in task order (bitwise reproducible: which
+//     wave ran which task does not matter), solves, applies the stop rules and re-opens the slot's counter — or, when the
+//     problem has converged, writes its outputs, draws the next problem from a global counter and stages it into the slot;
+//   * meanwhile every other wave works on the other slots.  There is no __syncthreads() after the first instruction and no
+//     wave ever waits while any resident problem has an open task.  G is chosen per problem and iteration from the number of
+//     problems the workgroup still holds: few, large tasks while every slot is busy (one reduction per task), single slabs when
+//     the queue runs dry, so that the last problems of a launch are iterated by all waves.
+// The hand-off is LDS only: `next_task` is parked at kQBusy while a slot is solved or re-staged (a late atomicAdd then
+// returns an invalid task whatever else changes), everything a task reads is written before the counter is re-opened
+// (workgroup-scope release / acquire), and a wave reads n, m, T only after it has drawn its task.
+// Every wave leaves when all slots are empty: a slot empties when its problem has converged and the global counter is
+// exhausted, which every problem reaches through max_iters at the latest; idle waves poll with s_sleep and give up after
+// kQTimeoutTicks of wall clock without any task (a can't-happen guard: the grid must always drain).
+//
+// LDS record of a chunk: its 16 targets (128 B) followed by its box (16 B) — 144 B.  A lane that compares its point with a
+// chunk reads eight 16-byte pairs at IMMEDIATE offsets from one address register (no per-target address arithmetic); lanes on
+// different chunks fall on the same banks only when their chunk ids agree modulo 16, and the 64 boxes of a ballot group are a
+// conflict-free stride.  Tail slots of the last chunk hold far, pairwise distinct points (finite distances ≈ 10³⁶: a real target
+// always wins; sources farther than 10¹⁵ from the origin take the exhaustive pass).
+//
+// float64-exact mode (args.src64 / tgt64 set): a slot then holds the float64 SOURCES themselves (the float32
+// point the search uses is their rounding, as in every other kernel) and, beside the float32 targets, the RESIDUAL of every
+// target coordinate t64 − f64(t32) as an int32 count of 2^(e − 54), e = frexp exponent of t32: the residual is a multiple of
+// that unit below 2²⁹ of them, so f64(t32) + ldexp(count, e − 54) IS the float64 target, bit for bit (8 bytes per target
+// instead of 16).  The moments of every iteration come from LDS; round 3's kernels re-read the float64 clouds from HBM in every
+// iteration (33 GB per C4 launch against 0.8 GB compulsory).  Near ties are rare and decided on the float64 targets read from the
+// sorted copy in memory.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "lslam_device.h"
+#include "lslam_kernels.h"
+#include "lslam_prune_common.h"
+
+namespace lslam {
+
+constexpr unsigned kQBusy = 0x40000000u;               // next_task while a slot is being solved / staged
+constexpr int kQCtlBytes = 256;
+constexpr long long kQTimeoutTicks = 400000000ll;      // 4 s of the 100 MHz wall clock
+constexpr int kQRec = kPruneChunk * 8 + 16;            // bytes per chunk record: 16 targets + the chunk's box
+constexpr int kQRows = 16;                             // rows of partial sums per slot = most tasks per problem and iteration
+constexpr float kQPad = 1.0e18f;                       // x of the padding targets (times 1 + slot/16), y = 0
+constexpr float kQFarD2 = 1.0e35f;                     // a best distance beyond this is not trusted (padding, overflow): exhaustive pass
+static_assert(kPruneChunk == 16, "the chunk record and the pair loop are written for 16 targets per chunk");
+
+struct QueueCtl {                                      // one per slot, in LDS
+  double T[16];
+  double err;
+  StopState stop;
+  int32_t problem;
+  int32_t n, m, nchunks, nslabs, ntasks, G;
+  uint32_t next_task;                                  // tasks handed out in this iteration (kQBusy: none to hand out)
+  uint32_t done_tasks;                                 // tasks completed in this iteration
+  int32_t state;                                       // 0 = empty for good, 1 = holds a problem, 2 = being staged for the first time
+  float Rt, Rs;                                        // float64-exact mode: largest |t|, |p| of the problem
+};
+static_assert(sizeof(QueueCtl) <= kQCtlBytes, "control block");
+
+__device__ __forceinline__ unsigned lds_load_u32(const uint32_t* p) {
+  return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ int lds_load_i32(const int32_t* p) {
+  return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+
+// float64-exact mode: a float64 coordinate from its float32 rounding and the residual count (see the header of this file)
+__device__ __forceinline__ int residual_count(double t64, float t32) {
+  const int e = __builtin_amdgcn_frexp_expf(t32);
+  return (int)rint(ldexp(t64 - (double)t32, 54 - e));
+}
+__device__ __forceinline__ double rebuild64(float t32, int count) {
+  const int e = __builtin_amdgcn_frexp_expf(t32);
+  return (double)t32 + ldexp((double)count, e - 54);
+}
+
+// byte offset of sorted target j inside a slot's records
+__device__ __forceinline__ unsigned rec_off(int j) { return (unsigned)(j >> 4) * kQRec + (unsigned)(j & 15) * 8u; }
+
+// One chunk against ONE point of this lane (a gather: every lane its own chunk), all eight pair reads in flight before the
+// first distance.  bd / pos: the smallest distance so far and the sorted position of its target.
+//   float32 mode: a pair's nearer target enters one compare against the best; `sec` records the VALUE at the last event "a
+//   distance equals the best so far" or "both distances of a pair are equal and take the lead".  The best only decreases, so
+//   after the search sec == bd exactly when two targets share the final minimum (decided by the pass over equal distances).
+//   float64-exact mode: the second smallest distance over everything evaluated is tracked (v_med3), the near-tie window needs it.
+template <bool F64>
+__device__ __forceinline__ void queue_eval_chunk(unsigned tile0, int chunk, float x, float y, float& bd, float& sec, int& pos, bool& tie) {
+  typedef float __attribute__((ext_vector_type(4))) Vec4;
+  typedef const __attribute__((address_space(3))) Vec4* LdsPair;
+  const unsigned rec = tile0 + (unsigned)chunk * kQRec;
+  Vec4 v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = *(LdsPair)(size_t)(rec + (unsigned)c * 16u);
+  __builtin_amdgcn_sched_barrier(0);
+  int kb = -1;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float d0 = dist2(x, y, v[c].x, v[c].y);
+    const float d1 = dist2(x, y, v[c].z, v[c].w);
+    if constexpr (F64) {
+      const bool lt0 = d0 < bd;
+      sec = __builtin_amdgcn_fmed3f(bd, sec, d0);
+      kb = lt0 ? 2 * c : kb;
+      bd = lt0 ? d0 : bd;
+      const bool lt1 = d1 < bd;
+      sec = __builtin_amdgcn_fmed3f(bd, sec, d1);
+      kb = lt1 ? 2 * c + 1 : kb;
+      bd = lt1 ? d1 : bd;
+    } else {
+      const bool c01 = d1 < d0;
+      const float mn = c01 ? d1 : d0;
+      const int kk = c01 ? 2 * c + 1 : 2 * c;
+      const bool lt = mn < bd;
+      const bool ev = (mn == bd) | ((d0 == d1) & lt);
+      sec = ev ? mn : sec;
+      kb = lt ? kk : kb;
+      bd = lt ? mn : bd;
+    }
+  }
+  pos = kb >= 0 ? chunk * kPruneChunk + kb : pos;
+}
+
+#ifdef LSLAM_QUEUE_PROFILE
+#define QUEUE_MARK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); prof[k] += now_ - pt; pt = now_; } while (0)
+#else
+#define QUEUE_MARK(k) do {} while (0)
+#endif
+
+template <bool F64>
+__global__ void __launch_bounds__(kIcpBatchMaxThreads, 4)      // ≤ 128 VGPRs: one workgroup of up to 16 waves per CU (the VALU is saturated by four waves per SIMD: tools/queue_stats.sh)
+icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
+  constexpr int CHUNK = kPruneChunk;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int Q = lay.Q;
+  const bool box = (args.flags & kFlagNormalize) != 0;
+  const int RS = box ? 13 : 9;                                 // doubles per row: Σp(2) Σq(2) Σpqᵀ(4) Σ‖p−q‖² [+ lo(2) hi(2)]
+  int* sh_fail = reinterpret_cast<int*>(smem + (size_t)Q * kQCtlBytes);
+  auto ctl_of = [&](int q) { return reinterpret_cast<QueueCtl*>(smem + (size_t)q * kQCtlBytes); };
+  auto slot_of = [&](int q) { return smem + lay.ctl_bytes + (size_t)q * lay.slot_bytes; };
+#ifdef LSLAM_QUEUE_PROFILE
+  unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime();
+  unsigned long long cnt[4] = {0, 0, 0, 0};                   // slabs searched, surviving boxes, list rounds, (point, chunk) list entries
+#define QUEUE_COUNT(k, v) do { cnt[k] += (v); } while (0)
+#else
+#define QUEUE_COUNT(k, v) do {} while (0)
+#endif
+
+  if (tid < Q) {
+    QueueCtl* c = ctl_of(tid);
+    c->state = 2; c->next_task = kQBusy; c->ntasks = 0; c->done_tasks = 0; c->problem = -1;
+  }
+  if (tid == 0) *sh_fail = 0;
+  __syncthreads();                                             // the only barrier of the kernel
+
+  // Slabs per task of a problem with `nslabs` slabs in its iteration `it`: three (one reduction per three slabs) while the problem
+  // is young, as few as the 16 rows of partial sums allow from its 8th iteration on — the long problems are what a launch ends on,
+  // and then all waves should iterate the few that are left.  A function of the problem alone — not of the batch it came in, its
+  // place in it, or timing: the grouping of the partial sums, hence every bit of a pair's result, is the same wherever and
+  // whenever the pair is solved (tests/test_gpu_shard.py demands that).
+  auto task_size = [&](int nslabs, int it) -> int {
+    if (lay.G > 0) return lay.G;
+    const int gmin = (nslabs + kQRows - 1) / kQRows;
+    int G = it < 8 ? (gmin > 3 ? gmin : 3) : gmin;
+    if (G > nslabs) G = nslabs;
+    return G < 1 ? 1 : G;
+  };
+
+  // ---- one wave: draw the next problem and stage it into slot q (or mark the slot empty for good) ----
+  auto refill = [&](int q) {
+    QueueCtl* c = ctl_of(q);
+    int p = 0;
+    if (lane == 0) p = (int)atomicAdd(&lay.queue[0], 1u);
+    p = __builtin_amdgcn_readfirstlane(p);
+    if (p >= S) {
+      if (lane == 0) __hip_atomic_store(&c->state, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // next_task stays kQBusy
+      return;
+    }
+    unsigned char* base = slot_of(q);
+    float4* slab_box = reinterpret_cast<float4*>(base + lay.slab_off);
+    int2* tdelta = reinterpret_cast<int2*>(base + lay.tdelta_off);
+    float2* sh_src = reinterpret_cast<float2*>(base + lay.src_off);
+    double2* sh_src64 = reinterpret_cast<double2*>(base + lay.src_off);
+    uint16_t* sh_prev = reinterpret_cast<uint16_t*>(base + lay.prev_off);
+    const int64_t s0 = args.src_off[p], t0 = args.tgt_off[p];
+    const int n = (int)(args.src_off[p + 1] - s0), m = (int)(args.tgt_off[p + 1] - t0);
+    const int64_t ss = (int64_t)p * sc.src_stride, ts = (int64_t)p * sc.tgt_stride;
+    const int nchunks = (m + CHUNK - 1) / CHUNK, nslabs = (n + kWave - 1) / kWave;
+    float tmax = 0.f, smax = 0.f;
+    for (int j = lane; j < nchunks * CHUNK; j += kWave) {
+      const float2 v = (j < m) ? sc.tgt_sorted[ts + j] : make_float2(kQPad * (1.f + 0.0625f * (float)(j & 15)), 0.f);
+      *reinterpret_cast<float2*>(base + rec_off(j)) = v;
+      if constexpr (F64) {
+        int2 d = make_int2(0, 0);
+        if (j < m) {
+          tmax = fmaxf(tmax, __builtin_fmaf(v.y, v.y, v.x * v.x));
+          const double2 td = sc.tgt64_sorted[ts + j];
+          d = make_int2(residual_count(td.x, v.x), residual_count(td.y, v.y));
+        }
+        tdelta[j] = d;
+      }
+    }
+    for (int i = lane; i < n; i += kWave) {
+      if constexpr (F64) {
+        const double2 pd = sc.src64_sorted[ss + i];
+        sh_src64[i] = pd;
+        const float vx = (float)pd.x, vy = (float)pd.y;
+        smax = fmaxf(smax, __builtin_fmaf(vy, vy, vx * vx));
+      } else {
+        sh_src[i] = sc.src_sorted[ss + i];
+      }
+      sh_prev[i] = 0xffff;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int cidx = lane; cidx < nchunks; cidx += kWave) {     // boxes over the real points only
+      float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+      const float2* rec = reinterpret_cast<const float2*>(base + (size_t)cidx * kQRec);
+      for (int k = 0; k < CHUNK && cidx * CHUNK + k < m; ++k) {
+        const float2 qv = rec[k];
+        x0 = fminf(x0, qv.x); y0 = fminf(y0, qv.y); x1 = fmaxf(x1, qv.x); y1 = fmaxf(y1, qv.y);
+      }
+      *reinterpret_cast<float4*>(base + (size_t)cidx * kQRec + CHUNK * 8) = make_float4(x0, y0, x1, y1);
+    }
+    // the box of every slab of 64 consecutive sources in the sources' own frame (lslam_icp_pruned.hip: per iteration the wave's
+    // box is this box under T)
+    for (int sl = 0; sl < nslabs; ++sl) {
+      const int i = sl * kWave + lane;
+      float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+      if (i < n) {
+        float2 v;
+        if constexpr (F64) { const double2 pd = sh_src64[i]; v = make_float2((float)pd.x, (float)pd.y); }
+        else v = sh_src[i];
+        x0 = v.x; y0 = v.y; x1 = v.x; y1 = v.y;
+      }
+      x0 = wave_min_dpp(x0); y0 = wave_min_dpp(y0); x1 = wave_max_dpp(x1); y1 = wave_max_dpp(y1);
+      if (lane == 0) slab_box[sl] = make_float4(x0, y0, x1, y1);
+    }
+    if constexpr (F64) { tmax = wave_max_dpp(tmax); smax = wave_max_dpp(smax); }
+    if (lane < 16) c->T[lane] = args.init_T[(int64_t)16 * p + lane];
+    if (lane == 0) __hip_atomic_store(&c->state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int G = task_size(nslabs, 0);
+    if (lane == 0) {
+      StopState st0; stop_init(st0);
+      c->stop = st0; c->err = 0.0;
+      c->problem = p; c->n = n; c->m = m; c->nchunks = nchunks; c->nslabs = nslabs;
+      c->G = G; c->ntasks = nslabs > 0 ? (nslabs + G - 1) / G : 1;
+      c->done_tasks = 0;
+      c->Rt = F64 ? sqrtf(tmax) * 1.0001f : 0.f;
+      c->Rs = F64 ? sqrtf(smax) * 1.0001f : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(&c->next_task, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // open
+  };
+
+  // ---- one wave: the slot's last task of this iteration is done — reduce, solve, stop rules; outputs and refill on convergence ----
+  auto finish = [&](int q) {
+    QueueCtl* c = ctl_of(q);
+    if (lane == 0) __hip_atomic_store(&c->next_task, kQBusy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    unsigned char* base = slot_of(q);
+    double* rows = reinterpret_cast<double*>(base + lay.rows_off);       // [rows_cap][RS] + 16 doubles of scratch
+    const int ntasks = lds_load_i32(&c->ntasks);
+    const int n = lds_load_i32(&c->n), nslabs = lds_load_i32(&c->nslabs);
+    double col;
+    {
+      const int cl = lane < RS ? lane : 0;
+      const bool is_sum = lane < 9, is_min = lane < 11;
+      col = rows[cl];
+      for (int w0 = 1; w0 < ntasks; w0 += 4) {                  // four rows per trip, their loads issued together; fixed order
+        double x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = rows[(size_t)(w0 + u < ntasks ? w0 + u : 0) * RS + cl];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!box) { col = (w0 + u < ntasks) ? col + x[u] : col; continue; }
+          const double s_ = col + x[u], lo_ = fmin(col, x[u]), hi_ = fmax(col, x[u]);
+          col = (w0 + u < ntasks) ? (is_sum ? s_ : (is_min ? lo_ : hi_)) : col;
+        }
+      }
+    }
+    double tot[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(col), k);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(col), k);
+      tot[k] = __hiloint2double(hi, lo);
+    }
+    Moments mo;
+    mo.n = (double)n;                                          // every source has a match: the count is the cloud's size
+    for (int i = 0; i < 3; ++i) { mo.sp[i] = 0.0; mo.sq[i] = 0.0; mo.lo[i] = 0.0; mo.hi[i] = 0.0; }
+    for (int i = 0; i < 9; ++i) mo.spq[i] = 0.0;
+    mo.sp[0] = tot[0]; mo.sp[1] = tot[1]; mo.sq[0] = tot[2]; mo.sq[1] = tot[3];
+    mo.spq[0] = tot[4]; mo.spq[1] = tot[5]; mo.spq[3] = tot[6]; mo.spq[4] = tot[7];
+    mo.sse = tot[8];
+    if (box) { mo.lo[0] = tot[9]; mo.lo[1] = tot[10]; mo.hi[0] = tot[11]; mo.hi[1] = tot[12]; }
+    double R[9], pb[3], qb[3];
+    step_parts(mo, true, R, pb, qb);
+    const double tn = step_times_prev_lane(R, pb, qb, c->T, rows + (size_t)kQRows * RS, lane);   // element `lane` of T_step·T_prev
+    const double err = error_from_moments(mo, box);
+    StopState st = c->stop;
+    const bool stop = stop_after_iteration(st, err, args.epsilon, args.stopping_thresh, args.max_iters);
+    if (lane < 16) c->T[lane] = tn;
+    QUEUE_MARK(2);
+    if (!stop) {
+      const int G = task_size(nslabs, st.executed);
+      if (lane == 0) {
+        c->stop = st; c->err = err; c->done_tasks = 0;
+        c->G = G; c->ntasks = nslabs > 0 ? (nslabs + G - 1) / G : 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&c->next_task, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    // next iteration
+      return;
+    }
+    const int p = lds_load_i32(&c->problem);
+    if (lane < 16) args.out_T[(int64_t)16 * p + lane] = tn;
+    if (lane == 0) { args.out_err[p] = err; args.out_iters[p] = st.executed; }
+    if (args.out_corr) {                                       // correspondences of the LAST iteration (icp.py:117, 187-189), caller's numbering
+      const int64_t s0 = args.src_off[p];
+      const int64_t ss = (int64_t)p * sc.src_stride, ts = (int64_t)p * sc.tgt_stride;
+      const uint16_t* sh_prev = reinterpret_cast<const uint16_t*>(base + lay.prev_off);
+      for (int i = lane; i < n; i += kWave) args.out_corr[s0 + sc.src_index[ss + i]] = sc.tgt_index[ts + sh_prev[i]];
+    }
+    refill(q);
+    QUEUE_MARK(3);
+  };
+
+  // ---- one wave: task t of slot q — G slabs of 64 sources: nearest neighbours, then their float64 moments ----
+  auto run_task = [&](int q, int t) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    QueueCtl* c = ctl_of(q);
+    unsigned char* base = slot_of(q);
+    const float4* slab_box = reinterpret_cast<const float4*>(base + lay.slab_off);
+    const int2* tdelta = reinterpret_cast<const int2*>(base + lay.tdelta_off);
+    const float2* sh_src = reinterpret_cast<const float2*>(base + lay.src_off);
+    const double2* sh_src64 = reinterpret_cast<const double2*>(base + lay.src_off);
+    uint16_t* sh_prev = reinterpret_cast<uint16_t*>(base + lay.prev_off);
+    double* rows = reinterpret_cast<double*>(base + lay.rows_off);
+    const int n = lds_load_i32(&c->n), m = lds_load_i32(&c->m), nchunks = lds_load_i32(&c->nchunks), nslabs = lds_load_i32(&c->nslabs);
+    const int ntasks = lds_load_i32(&c->ntasks), G = lds_load_i32(&c->G);
+    const int p = lds_load_i32(&c->problem);
+    double T[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) T[r][k] = wave_uniform(c->T[4 * r + k]);
+    NearTie nt = near_tie_setup(false, 0.f, 0.f, 0.f);
+    if constexpr (F64) {
+      const float Rt = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c->Rt)));
+      const float Rs = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c->Rs)));
+      nt = near_tie_setup(true, Rt, Rs, sqrtf((float)(T[0][0] * T[0][0] + T[0][1] * T[0][1] + T[1][0] * T[1][0] + T[1][1] * T[1][1])) * 1.0001f);
+    }
+    // the bound a chunk must beat: the lane's best itself, or in float64-exact mode everything within its near-tie window;
+    // divided by the safety factor once instead of multiplying every box distance by it (1.00002 > 1 / 0.99999)
+    auto reach = [&](float b) { return (F64 ? __builtin_fmaf(b, nt.K1, nt.C) : b) * 1.00002f; };
+    typedef const __attribute__((address_space(3))) unsigned char* LdsBytes;
+    const unsigned tile0 = (unsigned)(size_t)(LdsBytes)(const void*)base;
+    const int64_t ts = (int64_t)p * sc.tgt_stride;
+    const uint16_t* __restrict__ tidx = sc.tgt_index + ts;
+    const double2* __restrict__ gtgt64 = F64 ? sc.tgt64_sorted + ts : nullptr;
+    auto target_at = [&](int j) { return *reinterpret_cast<const float2*>(base + rec_off(j)); };
+    auto box_at = [&](int cidx) { return *reinterpret_cast<const float4*>(base + (size_t)cidx * kQRec + CHUNK * 8); };
+
+    const int slab_lo = t * G, slab_hi = min(slab_lo + G, nslabs);
+    for (int slab = slab_lo; slab < slab_hi; ++slab) {
+      const int i = slab * kWave + lane;
+      const bool owns = i < n;
+      QUEUE_COUNT(0, 1);
+      float ax = 0.f, ay = 0.f;
+      if (owns) {
+        float2 v;
+        if constexpr (F64) { const double2 pd = sh_src64[i]; v = make_float2((float)pd.x, (float)pd.y); }
+        else v = sh_src[i];
+        ax = (float)(T[0][0] * (double)v.x + T[0][1] * (double)v.y + T[0][3]);      // icp.py:116
+        ay = (float)(T[1][0] * (double)v.x + T[1][1] * (double)v.y + T[1][3]);
+      }
+      // the wave's box: the slab's box under T, widened by 16 ulps of the magnitudes involved (lslam_icp_pruned.hip)
+      float wx0, wy0, wx1, wy1;
+      {
+        const float4 sb = slab_box[slab];
+        const float r00 = (float)T[0][0], r01 = (float)T[0][1], r03 = (float)T[0][3], r10 = (float)T[1][0], r11 = (float)T[1][1], r13 = (float)T[1][3];
+        const float mx = fmaxf(fabsf(sb.x), fabsf(sb.z)), my = fmaxf(fabsf(sb.y), fabsf(sb.w));
+        const float ex = 1e-6f * (fabsf(r00) * mx + fabsf(r01) * my + fabsf(r03)) + 1e-30f;
+        const float ey = 1e-6f * (fabsf(r10) * mx + fabsf(r11) * my + fabsf(r13)) + 1e-30f;
+        wx0 = r03 + fminf(r00 * sb.x, r00 * sb.z) + fminf(r01 * sb.y, r01 * sb.w) - ex;
+        wx1 = r03 + fmaxf(r00 * sb.x, r00 * sb.z) + fmaxf(r01 * sb.y, r01 * sb.w) + ex;
+        wy0 = r13 + fminf(r10 * sb.x, r10 * sb.z) + fminf(r11 * sb.y, r11 * sb.w) - ey;
+        wy1 = r13 + fmaxf(r10 * sb.x, r10 * sb.z) + fmaxf(r11 * sb.y, r11 * sb.w) + ey;
+      }
+      // ---- seed: the chunk of last iteration's match (first iteration: of the target at the same relative rank), compared
+      // target by target by the lane itself: an exact bound before any box test
+      float bd = owns ? INFINITY : -INFINITY;                  // lanes without a point never ask for a chunk
+      float sec = INFINITY;
+      int pos = 0, own = -1;
+      bool tie = false;
+      if (owns) {
+        const int pv = sh_prev[i];
+        own = (pv != 0xffff ? pv : (int)(((long long)i * m) / n)) / CHUNK;
+        queue_eval_chunk<F64>(tile0, own, ax, ay, bd, sec, pos, tie);
+      }
+      const float wb = reach(wave_max_dpp(bd));                // no lane can ask for a chunk farther than this from the wave's box
+      // ---- sweep: 64 chunk boxes tested at once, one per lane, against the wave's box; the survivors against every lane's own
+      // point and current bound → a 64-bit list per lane, which the lane works through
+      for (int c0 = 0; c0 < nchunks; c0 += 64) {
+        bool cand = false;
+        if (c0 + lane < nchunks) {
+          const float4 b = box_at(c0 + lane);
+          const float dx = fmaxf(fmaxf(b.x - wx1, wx0 - b.z), 0.f);
+          const float dy = fmaxf(fmaxf(b.y - wy1, wy0 - b.w), 0.f);
+          cand = wb >= __builtin_fmaf(dy, dy, dx * dx);
+        }
+        unsigned long long todo = __ballot(cand);
+        if (!todo) continue;
+        QUEUE_COUNT(1, __builtin_popcountll(todo));
+        unsigned list_lo = 0u, list_hi = 0u;
+        const float rb = reach(bd);                            // the seed's bound: a chunk evaluated later can only lower it
+        while (todo) {
+          // four surviving boxes per trip, their (wave-uniform) reads issued together: one LDS round trip per box, each waited for
+          // in turn, was the longest dependent chain of the search
+          int tb[4];
+          bool ok[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            ok[u] = todo != 0ull;
+            tb[u] = ok[u] ? __builtin_ctzll(todo) : 0;
+            todo &= todo - 1;                                  // 0 stays 0
+          }
+          float4 b[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) b[u] = box_at(c0 + tb[u]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float ox = fmaxf(fmaxf(b[u].x - ax, ax - b[u].z), 0.f);
+            const float oy = fmaxf(fmaxf(b[u].y - ay, ay - b[u].w), 0.f);
+            const bool need = ok[u] && rb >= __builtin_fmaf(oy, oy, ox * ox);
+            // the bit's half is wave-uniform: one select and one or
+            const unsigned bit = need ? (1u << (tb[u] & 31)) : 0u;
+            if (tb[u] < 32) list_lo |= bit; else list_hi |= bit;
+          }
+        }
+        // the seed chunk was compared already: a second visit would read as a tie of the point with itself
+        {
+          const int rel = own - c0;
+          const unsigned clr = 1u << (rel & 31);
+          if (rel >= 0 && rel < 32) list_lo &= ~clr;
+          if (rel >= 32 && rel < 64) list_hi &= ~clr;
+        }
+        unsigned long long list = ((unsigned long long)list_hi << 32) | list_lo;
+#ifdef LSLAM_QUEUE_PROFILE
+        { unsigned long long items = (unsigned long long)__builtin_popcountll(list);
+          for (int o = 32; o > 0; o >>= 1) items += __shfl_xor(items, o, 64);
+          QUEUE_COUNT(3, items); }
+#endif
+        while (__any(list != 0ull)) {
+          QUEUE_COUNT(2, 1);
+          if (list != 0ull) {
+            const int tbit = __builtin_ctzll(list);
+            list &= list - 1;
+            queue_eval_chunk<F64>(tile0, c0 + tbit, ax, ay, bd, sec, pos, tie);
+          }
+        }
+      }
+      bool near = false;
+      if constexpr (F64) { near = owns && bd < kQFarD2 && sec <= near_lim(bd, nt); tie = near; }
+      else tie = owns && (sec == bd || !(bd < kQFarD2));
+      if constexpr (F64) {
+        // a best distance that cannot be trusted (magnitudes near the padding's): every target is a candidate
+        const bool far = owns && !(bd < kQFarD2);
+        // ---- near ties: every target whose float32 distance is within lim of the winner's is compared in float64 on the float64
+        // points (lowest original index on float64 ties); chunks walked with the flagged lanes' own points and windows
+        if (__any(tie || far)) {
+          if (lay.debug && lane == 0) atomicAdd(&lay.queue[2], 1u);
+          const float lim = far ? INFINITY : (near ? near_lim(bd, nt) : -INFINITY);
+          double adx = 0.0, ady = 0.0;
+          if (near || far) {
+            const double2 pd = sh_src64[i];
+            adx = T[0][0] * pd.x + T[0][1] * pd.y + T[0][3];
+            ady = T[1][0] * pd.x + T[1][1] * pd.y + T[1][3];
+          }
+          double bv = INFINITY;
+          int bo = 0x7fffffff, bp = pos;
+          for (int cc = 0; cc < nchunks; ++cc) {
+            const float4 b = box_at(cc);
+            const float ox = fmaxf(fmaxf(b.x - ax, ax - b.z), 0.f);
+            const float oy = fmaxf(fmaxf(b.y - ay, ay - b.w), 0.f);
+            if (!__any(lim * 1.00002f >= __builtin_fmaf(oy, oy, ox * ox))) continue;
+            for (int k = 0; k < CHUNK; ++k) {
+              const int j = cc * CHUNK + k;
+              if (j >= m) break;
+              const float2 qv = target_at(j);
+              if (dist2(ax, ay, qv.x, qv.y) <= lim) {          // rare: a candidate of this lane
+                const int o = tidx[j];
+                const double2 td = gtgt64[j];
+                const double dx = adx - td.x, dy = ady - td.y;
+                const double e = dx * dx + dy * dy;
+                if (e < bv || (e == bv && o < bo)) { bv = e; bo = o; bp = j; }
+              }
+            }
+          }
+          if (near || far) pos = bp;
+        }
+      } else if (__any(tie)) {
+        // ---- equal minima (duplicate or equidistant points): among the targets at exactly the smallest distance the lowest
+        // ORIGINAL index wins.  The search is exact, so bd is the smallest distance; a lane whose bd cannot be trusted takes the
+        // minimum over all real targets first.
+        if (lay.debug && lane == 0) atomicAdd(&lay.queue[2], 1u);
+        if (__any(tie && !(bd < kQFarD2))) {
+          float b2 = INFINITY;
+          for (int j = 0; j < m; ++j) { const float2 qv = target_at(j); b2 = fminf(b2, dist2(ax, ay, qv.x, qv.y)); }
+          if (tie && !(bd < kQFarD2)) bd = b2;
+        }
+        int oidx = 0x7fffffff;
+        for (int j0 = 0; j0 < m; j0 += 8) {
+          float2 qv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) qv[u] = target_at(j0 + u < m ? j0 + u : m - 1);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (tie && j0 + u < m && dist2(ax, ay, qv[u].x, qv[u].y) == bd) {      // rare
+              const int o = tidx[j0 + u];
+              if (o < oidx) { oidx = o; pos = j0 + u; }
+            }
+          }
+        }
+      }
+      if (owns) sh_prev[i] = (uint16_t)pos;
+    }
+    QUEUE_MARK(0);
+
+    // ---- float64 moments of the task's matched pairs (kept apart from the search: the accumulators are not live while it runs)
+    double a[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a[k] = 0.0;
+    double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
+    for (int slab = slab_lo; slab < slab_hi; ++slab) {
+      const int i = slab * kWave + lane;
+      if (i < n) {
+        const int ps = sh_prev[i];
+        double x, y, qx, qy;
+        const float2 qv = target_at(ps);
+        if constexpr (F64) {
+          const double2 sp = sh_src64[i];
+          const int2 dv = tdelta[ps];
+          x = sp.x; y = sp.y;
+          qx = rebuild64(qv.x, dv.x); qy = rebuild64(qv.y, dv.y);
+        } else {
+          const float2 v = sh_src[i];
+          x = (double)v.x; y = (double)v.y;
+          qx = (double)qv.x; qy = (double)qv.y;
+        }
+        const double px = T[0][0] * x + T[0][1] * y + T[0][3];
+        const double py = T[1][0] * x + T[1][1] * y + T[1][3];
+        a[0] += px; a[1] += py; a[2] += qx; a[3] += qy;
+        a[4] += px * qx; a[5] += px * qy; a[6] += py * qx; a[7] += py * qy;
+        const double dx = px - qx, dy = py - qy;
+        double e = 0.0;
+        e += dx * dx; e += dy * dy;
+        a[8] += e;
+        if (box) {
+          lo[0] = fmin(lo[0], fmin(px, qx)); lo[1] = fmin(lo[1], fmin(py, qy));
+          hi[0] = fmax(hi[0], fmax(px, qx)); hi[1] = fmax(hi[1], fmax(py, qy));
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a[k] = wave_sum_dpp_last(a[k]);
+    if (box) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { lo[k] = wave_min_dpp_last(lo[k]); hi[k] = wave_max_dpp_last(hi[k]); }
+    }
+    if (lane == 63) {
+      double* row = rows + (size_t)t * RS;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) row[k] = a[k];
+      if (box) { row[9] = lo[0]; row[10] = lo[1]; row[11] = hi[0]; row[12] = hi[1]; }
+    }
+    QUEUE_MARK(1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    unsigned d = 0;
+    if (lane == 0) d = atomicAdd(&c->done_tasks, 1u) + 1u;
+    d = __builtin_amdgcn_readfirstlane(d);
+    if (d == (unsigned)ntasks) finish(q);
+  };
+
+  // ---- first problems, then the queue ----
+  for (int q = wave; q < Q; q += nwaves) refill(q);
+  QUEUE_MARK(3);
+  int pref = wave % Q;
+  long long idle_since = -1;
+  for (;;) {
+    bool got = false, alive = false;
+    for (int k = 0; k < Q; ++k) {
+      int q = pref + k;
+      if (q >= Q) q -= Q;
+      QueueCtl* c = ctl_of(q);
+      alive |= lds_load_i32(&c->state) != 0;
+      const unsigned nt_ = lds_load_u32(&c->next_task);
+      if (nt_ < (unsigned)lds_load_i32(&c->ntasks)) {
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(&c->next_task, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t < (unsigned)lds_load_i32(&c->ntasks)) {
+          QUEUE_MARK(4);
+          run_task(q, (int)t);
+          got = true; pref = q;
+          break;
+        }
+      }
+    }
+    if (got) { idle_since = -1; continue; }
+    if (!alive) break;
+    if (lds_load_i32(sh_fail)) break;
+    const long long now = (long long)wall_clock64();
+    if (idle_since < 0) idle_since = now;
+    else if (now - idle_since > kQTimeoutTicks) {             // can't happen on a healthy device: leave so that the grid drains
+      if (lane == 0) { __hip_atomic_store(sh_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicAdd(&lay.queue[1], 1u); }
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  QUEUE_MARK(4);
+#ifdef LSLAM_QUEUE_PROFILE
+  // cycles per phase and search statistics summed over the waves of the launch (printed by the launcher under LSLAM_DEBUG)
+  if (lay.debug && lane == 0) {
+    for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(lay.queue + 4) + k, prof[k]);
+    for (int k = 0; k < 4; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(lay.queue + 4) + 6 + k, cnt[k]);
+  }
+#endif
+}
+
+// ---- launch ------------------------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n, hipStream_t stream) {
+  if ((a.src64 == nullptr) != (a.tgt64 == nullptr)) return hipErrorInvalidValue;
+  const bool f64 = a.src64 != nullptr;
+  const bool box = (a.flags & kFlagNormalize) != 0;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    if (cus <= 0) cus = 256;
+  }
+  constexpr size_t kLdsPerCu = 160 * 1024;
+  const int RS = box ? 13 : 9;
+  const int nchunks = (int)((max_tgt_n + kPruneChunk - 1) / kPruneChunk);
+  const int padded = nchunks * kPruneChunk;
+  const int nslabs = (int)((max_src_n + 63) / 64);
+  auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  QueueLayout lay{};
+  const int rows_cap = kQRows;
+  size_t off = (size_t)nchunks * kQRec;
+  lay.slab_off = (uint32_t)off; off += (size_t)(nslabs > 0 ? nslabs : 1) * sizeof(float4);
+  lay.tdelta_off = (uint32_t)off; if (f64) off += (size_t)padded * sizeof(float2);
+  lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * (f64 ? sizeof(double2) : sizeof(float2)));
+  lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));
+  lay.rows_off = (uint32_t)off; off += sizeof(double) * ((size_t)rows_cap * RS + 16);
+  const size_t slot = up(off);
+  lay.rows_cap = rows_cap;
+  // geometry: one workgroup of W waves per CU holding Q slots
+  int W = env_int("LSLAM_ICP_QUEUE_WAVES", 16);
+  if (W < 1 || W > kIcpBatchMaxWaves) W = 16;
+  int Q = 1;
+  while (Q < 16 && (size_t)(Q + 1) * kQCtlBytes + 64 + (size_t)(Q + 1) * slot <= kLdsPerCu) ++Q;
+  {
+    // fewer problems than the chip has slots: spread them over the CUs
+    const int64_t slots_needed = ((int64_t)S + cus - 1) / cus;
+    if (Q > slots_needed) Q = (int)(slots_needed > 0 ? slots_needed : 1);
+    const int q_forced = env_int("LSLAM_ICP_QUEUE_Q", 0);
+    if (q_forced > 0 && q_forced < Q) Q = q_forced;
+  }
+  if (Q * (nslabs > 0 ? nslabs : 1) < W) W = Q * (nslabs > 0 ? nslabs : 1);      // no more waves than tasks can ever be open
+  lay.slot_bytes = (uint32_t)slot;
+  lay.ctl_bytes = (uint32_t)up((size_t)Q * kQCtlBytes + 64);
+  lay.Q = Q;
+  lay.G = env_int("LSLAM_ICP_QUEUE_G", 0);                     // 0: chosen per problem and iteration (task_size)
+  if (lay.G > 0 && (nslabs + lay.G - 1) / lay.G > rows_cap) lay.G = (nslabs + rows_cap - 1) / rows_cap;
+  lay.queue = sc.queue;
+  lay.debug = getenv("LSLAM_DEBUG") ? 1 : 0;
+  const size_t smem = lay.ctl_bytes + (size_t)Q * slot;
+  if (smem > kLdsPerCu) return hipErrorInvalidValue;
+  int grid = (S + Q - 1) / Q;
+  if (grid > cus) grid = cus;
+  const int threads = W * 64;
+  if (lay.debug) {
+    unsigned long long h[14];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(h, sc.queue, 112, hipMemcpyDeviceToHost);
+    const unsigned* hu = reinterpret_cast<const unsigned*>(h);
+    fprintf(stderr, "[lslam] queue kernel, previous launch: problems drawn %u, timeouts %u, tie passes %u\n", hu[0], hu[1], hu[2]);
+#ifdef LSLAM_QUEUE_PROFILE
+    double tot = 0; for (int k = 0; k < 6; ++k) tot += (double)h[2 + k];
+    if (tot > 0) fprintf(stderr, "[lslam] queue kernel, share of wave cycles: search %.3f  moments %.3f  reduce+solve %.3f  outputs+staging %.3f  idle %.3f\n",
+                         h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot);
+    if (h[8] > 0) fprintf(stderr, "[lslam] queue kernel, per slab searched: %.2f surviving boxes, %.2f list rounds, %.2f (point, chunk) entries; %.0f cycles per slab\n",
+                          (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], tot / h[8]);
+#endif
+    fprintf(stderr, "[lslam] icp_queue_kernel: %d workgroups x %d waves, %d slots of %zu B (%zu B LDS), %d rows per slot, %s\n",
+            grid, W, Q, slot, smem, rows_cap, f64 ? "float64-exact" : "float32");
+  }
+  hipError_t e = hipMemsetAsync(sc.queue, 0, 128, stream);
+  if (e != hipSuccess) return e;
+  auto launch = [&](auto kernel) -> hipError_t {
+    hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (ee != hipSuccess) return ee;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), smem, stream, a, sc, lay, S);
+    return hipGetLastError();
+  };
+  return f64 ? launch(icp_queue_kernel<true>) : launch(icp_queue_kernel<false>);
+}
+
+}  // namespace lslam

@@ -74,7 +74,17 @@ struct PruneScratch {                      // Morton-sorted copies: problem k ow
   // float64-exact mode: the float64 clouds in the same sorted order (written by icp_sort_kernel), so that the moments read
   // them sequentially / from neighbouring lines instead of gathering 16 bytes per point from the caller's order
   double2* src64_sorted; double2* tgt64_sorted;
+  unsigned* queue;                         // 256 bytes: [0] next problem of the task-queue kernel, [1] waves that gave up waiting, [2] tie passes, [4…] profile
 };
+// lslam_icp_queue.hip: byte offsets inside one LDS slot (the target tile is at 0), slots per workgroup, slabs per task
+struct QueueLayout {
+  uint32_t slot_bytes, ctl_bytes;
+  uint32_t slab_off, tdelta_off, src_off, prev_off, rows_off;      // the chunk records (16 targets + box each) start at 0
+  int32_t Q, G, rows_cap;                                          // G = 0: task size chosen per problem and iteration
+  unsigned* queue;
+  int32_t debug;
+};
+hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n, hipStream_t stream);
 struct PruneLayout { uint32_t aabb_off, src_off, prev_off, red_off; unsigned* debug_counter; uint32_t slab_off; };   // slab_off: planar kernel only
 bool icp_pruned_supported(int dim, int64_t max_src_n, int64_t max_tgt_n);
 hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n,
@@ -198,6 +208,7 @@ struct CoopArgs {
   double epsilon, stopping_thresh;
   int32_t max_iters;
   uint32_t tile_bytes, tile64_bytes, box_bytes, gran_bytes;   // filled by the launcher
+  unsigned long long timeout_ticks;                           // filled by the launcher: bound of one hand-off wait (100 MHz ticks)
 };
 bool icp_coop_supported(int dim, int64_t n, int64_t m, bool f64);
 size_t icp_coop_gran_bytes(int dim, int64_t n);

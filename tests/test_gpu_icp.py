@@ -1081,3 +1081,93 @@ def test_float64_exact_mode_on_clouds_made_of_near_ties(icp, dim, monkeypatch, p
             assert it[0] == 2
             np.testing.assert_array_equal(corr, oracles[k][2], err_msg=f"whole-chip flags={flags} coop={coop} case {k}")
             np.testing.assert_allclose(T, oracles[k][0], atol=1e-9)
+
+
+# ---- the co-resident one-launch kernel must degrade, never fail (lslam.h: lslam_icp_coop_fallbacks) ------------------------
+def _c2_like_pair(seed=5, n=1081):
+    rng = np.random.default_rng(seed)
+    ang = np.linspace(-2.35, 2.35, n)
+    rad = 5.0 + np.sin(3 * ang) + 0.6 * np.cos(7 * ang) + rng.normal(0, 0.004, n)
+    tgt = np.column_stack((rad * np.cos(ang), rad * np.sin(ang)))
+    th, t = 0.03, np.array([0.05, 0.01])
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    return (tgt - t) @ R + rng.normal(0, 0.003, tgt.shape), tgt
+
+
+def test_co_resident_launch_falls_back_instead_of_failing(icp, prec, monkeypatch):
+    """a hand-off bound of zero makes the first wait of the co-resident kernel give up: the SAME call must then finish on the
+    launch-per-iteration path with the same result; a CU count too small for the grid must skip the co-resident path"""
+    from lidar_slam_amd import _lib
+    src, tgt = _c2_like_pair()
+    src, tgt = prec.cast(src), prec.cast(tgt)
+    monkeypatch.setenv("LSLAM_ICP_PRUNE", "0")
+    ref = icp.run_icp(src, tgt, epsilon=0.0, stopping_thresh=0.0, max_iters=11, return_error=True, return_correspondences=True)
+    before = _lib.lib().lslam_icp_coop_fallbacks()
+    monkeypatch.setenv("LSLAM_ICP_COOP_TIMEOUT_US", "0")
+    got = icp.run_icp(src, tgt, epsilon=0.0, stopping_thresh=0.0, max_iters=11, return_error=True, return_correspondences=True)
+    monkeypatch.delenv("LSLAM_ICP_COOP_TIMEOUT_US")
+    assert _lib.lib().lslam_icp_coop_fallbacks() == before + 1, "the zero bound did not force the detour"
+    assert np.abs(got[0] - ref[0]).max() < 1e-9 and abs(got[1] - ref[1]) < 1e-9 * max(1.0, ref[1])
+    assert np.array_equal(got[2], ref[2])
+    # a device with fewer CUs than twice the grid (17 workgroups here): the co-resident path is not taken at all
+    monkeypatch.setenv("LSLAM_ICP_COOP_MAX_CUS", "32")
+    monkeypatch.setenv("LSLAM_ICP_COOP_TIMEOUT_US", "0")          # would force a detour if the path were taken
+    got2 = icp.run_icp(src, tgt, epsilon=0.0, stopping_thresh=0.0, max_iters=11, return_error=True, return_correspondences=True)
+    assert _lib.lib().lslam_icp_coop_fallbacks() == before + 1
+    assert np.abs(got2[0] - ref[0]).max() < 1e-9 and np.array_equal(got2[2], ref[2])
+
+
+def test_single_pair_while_another_stream_holds_the_chip(icp, prec):
+    """a long all-pairs batch occupies every CU from one stream while run_icp's device entry point solves a LiDAR-sized pair on
+    another: whichever path the library ends on, the answer is the uncontended one (and the oracle's)"""
+    import torch
+    from lidar_slam_amd import batch as B
+    from oracle import icp_oracle
+    src, tgt = _c2_like_pair(seed=9)
+    dev = torch.device("cuda", 0)
+    d_src32 = torch.from_numpy(src.astype(np.float32)).to(dev); d_tgt32 = torch.from_numpy(tgt.astype(np.float32)).to(dev)
+    d_src64 = torch.from_numpy(src).to(dev) if prec.name == "f64" else None
+    d_tgt64 = torch.from_numpy(tgt).to(dev) if prec.name == "f64" else None
+    if prec.name == "f64":
+        d_src32 = d_src64.float(); d_tgt32 = d_tgt64.float()
+    n = src.shape[0]
+    kw = dict(epsilon=1e-3, prune=False, d_src64=d_src64.data_ptr() if d_src64 is not None else None,
+              d_tgt64=d_tgt64.data_ptr() if d_tgt64 is not None else None)
+    quiet = B.icp_large_dev(d_src32.data_ptr(), n, d_tgt32.data_ptr(), n, 2, np.eye(4), **kw)
+    # the load: 2048 problems of 2048 x 2048 points, 40 forced all-pairs iterations (tens of milliseconds of a full chip)
+    S, P = 2048, 2048
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    big = (torch.rand((S * P, 2), device=dev, generator=g) * 20 - 10).contiguous()
+    off = (torch.arange(S + 1, device=dev, dtype=torch.int64) * P).contiguous()
+    init = torch.eye(4, dtype=torch.float64, device=dev).repeat(S, 1, 1).contiguous()
+    oT = torch.empty((S, 4, 4), dtype=torch.float64, device=dev); oe = torch.empty(S, dtype=torch.float64, device=dev)
+    oi = torch.empty(S, dtype=torch.int32, device=dev)
+    load_stream, pair_stream = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    B.icp_batch_dev(big.data_ptr(), off.data_ptr(), big.data_ptr(), off.data_ptr(), 2, init.data_ptr(), S, P, P, oT.data_ptr(),
+                    oe.data_ptr(), oi.data_ptr(), None, epsilon=0.0, max_iters=39, stopping_thresh=0.0, stream=load_stream.cuda_stream, prune=False)
+    busy = B.icp_large_dev(d_src32.data_ptr(), n, d_tgt32.data_ptr(), n, 2, np.eye(4), stream=pair_stream.cuda_stream, **kw)
+    torch.cuda.synchronize()
+    assert int(oi.min().item()) == 40                                   # the load really ran
+    assert busy[2] == quiet[2] and np.abs(busy[0] - quiet[0]).max() < 1e-12 and abs(busy[1] - quiet[1]) < 1e-12 * max(1.0, quiet[1])
+    ref = icp_oracle.run_icp_full(src if prec.name == "f64" else src.astype(np.float32).astype(np.float64),
+                                  tgt if prec.name == "f64" else tgt.astype(np.float32).astype(np.float64),
+                                  epsilon=1e-3, recipe=prec.recipe, nn="brute")
+    assert busy[2] == ref.iterations and np.abs(busy[0] - ref.T).max() < 1e-9
+
+
+def test_release_thread_resources_and_continue(icp, prec):
+    """lslam_release_thread_resources hands every per-thread workspace back; the next calls allocate again and agree"""
+    import lidar_slam_amd
+    from lidar_slam_amd.batch import icp_batch
+    src, tgt = _c2_like_pair(seed=2, n=700)
+    clouds = [prec.cast(src), prec.cast(tgt)]
+    flat, off = prec.pack(clouds)
+    first = icp_batch(flat, np.array([off[0], off[1]]), flat, np.array([off[1], off[2]]), np.eye(4)[None], epsilon=1e-3, prune=True)
+    one = icp.run_icp(clouds[0], clouds[1], epsilon=1e-3)
+    lidar_slam_amd.release_thread_resources()
+    lidar_slam_amd.release_thread_resources()                               # idempotent
+    again = icp_batch(flat, np.array([off[0], off[1]]), flat, np.array([off[1], off[2]]), np.eye(4)[None], epsilon=1e-3, prune=True)
+    one_again = icp.run_icp(clouds[0], clouds[1], epsilon=1e-3)
+    assert np.array_equal(first.T, again.T) and np.array_equal(first.iterations, again.iterations)
+    assert np.array_equal(one, one_again)
