@@ -14,9 +14,10 @@
 //     wave ever waits while any resident problem has an open task.  G is chosen per problem and iteration from the number of
 //     problems the workgroup still holds: few, large tasks while every slot is busy (one reduction per task), single slabs when
 //     the queue runs dry, so that the last problems of a launch are iterated by all waves.
-// The hand-off is LDS only: `next_task` is parked at kQBusy while a slot is solved or re-staged (a late atomicAdd then
-// returns an invalid task whatever else changes), everything a task reads is written before the counter is re-opened
-// (workgroup-scope release / acquire), and a wave reads n, m, T only after it has drawn its task.
+// The hand-off is LDS only: a slot's ticket word (tasks of the round | tasks handed out) is parked at kQClosed while the slot is
+// solved or re-staged (a late atomicAdd then returns an invalid ticket whatever else changes), everything a task reads is written
+// before the ticket is re-opened (workgroup-scope release / acquire), and a wave reads n, m, T only after it has drawn its task.
+// A wave looks at the tickets of all slots with one load (lane q: slot q) and at a slot's control block with another.
 // Every wave leaves when all slots are empty: a slot empties when its problem has converged and the global counter is
 // exhausted, which every problem reaches through max_iters at the latest; idle waves poll with s_sleep and give up after
 // kQTimeoutTicks of wall clock without any task (a can't-happen guard: the grid must always drain).
@@ -36,6 +37,7 @@
 // sorted copy in memory.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stddef.h>
 #include <stdlib.h>
 
 #include "lslam_device.h"
@@ -44,27 +46,31 @@
 
 namespace lslam {
 
-constexpr unsigned kQBusy = 0x40000000u;               // next_task while a slot is being solved / staged
 constexpr int kQCtlBytes = 256;
 constexpr long long kQTimeoutTicks = 400000000ll;      // 4 s of the 100 MHz wall clock
 constexpr int kQRec = kPruneChunk * 8 + 16;            // bytes per chunk record: 16 targets + the chunk's box
-constexpr int kQRows = 16;                             // rows of partial sums per slot = most tasks per problem and iteration
+constexpr int kQMomentSlabs = 16;                      // slabs of 64 pairs per row of float64 partial sums
+constexpr int kQRows = 8;                              // rows per slot: problems of up to 8192 sources
 constexpr float kQPad = 1.0e18f;                       // x of the padding targets (times 1 + slot/16), y = 0
 constexpr float kQFarD2 = 1.0e35f;                     // a best distance beyond this is not trusted (padding, overflow): exhaustive pass
 static_assert(kPruneChunk == 16, "the chunk record and the pair loop are written for 16 targets per chunk");
 
-struct QueueCtl {                                      // one per slot, in LDS
-  double T[16];
+struct QueueCtl {                                      // one per slot, in LDS; a task reads the whole block with ONE 64-lane load (ctl_*)
+  double T[16];                                        // dwords 0..31
   double err;
   StopState stop;
   int32_t problem;
-  int32_t n, m, nchunks, nslabs, ntasks, G;
-  uint32_t next_task;                                  // tasks handed out in this iteration (kQBusy: none to hand out)
-  uint32_t done_tasks;                                 // tasks completed in this iteration
-  int32_t state;                                       // 0 = empty for good, 1 = holds a problem, 2 = being staged for the first time
+  int32_t n, m, nchunks, nslabs, G, phase;             // phase 0: search tasks of G slabs, 1: moment tasks of kQMomentSlabs slabs
+  uint32_t done_tasks;                                 // tasks completed in this round
   float Rt, Rs;                                        // float64-exact mode: largest |t|, |p| of the problem
 };
 static_assert(sizeof(QueueCtl) <= kQCtlBytes, "control block");
+#define QCTL_DWORD(field) (int)(offsetof(QueueCtl, field) / 4)
+// Ticket word of a slot: tasks of the current round in the high half, tasks handed out in the low half; kQClosed while the slot
+// is being solved or staged (a late atomicAdd then returns an invalid ticket whatever else changes).  State word: 0 = empty for
+// good, 1 = holds a problem, 2 = being staged for the first time.  Both live in arrays of their own, one word per slot, so that a
+// wave looks at all slots with one load.
+constexpr unsigned kQClosed = 0x00008000u;
 
 __device__ __forceinline__ unsigned lds_load_u32(const uint32_t* p) {
   return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -82,6 +88,14 @@ __device__ __forceinline__ double rebuild64(float t32, int count) {
   const int e = __builtin_amdgcn_frexp_expf(t32);
   return (double)t32 + ldexp((double)count, e - 54);
 }
+
+// a slot's control block through ONE load: lane k holds dword k, fields come out with v_readlane (wave-uniform, in scalar registers)
+__device__ __forceinline__ int ctl_load(const QueueCtl* c, int lane) {
+  return __hip_atomic_load(reinterpret_cast<const int*>(c) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#define CTL_INT(cw, field) __builtin_amdgcn_readlane(cw, QCTL_DWORD(field))
+#define CTL_FLOAT(cw, field) __int_as_float(__builtin_amdgcn_readlane(cw, QCTL_DWORD(field)))
+#define CTL_T(cw, k) __hiloint2double(__builtin_amdgcn_readlane(cw, 2 * (k) + 1), __builtin_amdgcn_readlane(cw, 2 * (k)))
 
 // byte offset of sorted target j inside a slot's records
 __device__ __forceinline__ unsigned rec_off(int j) { return (unsigned)(j >> 4) * kQRec + (unsigned)(j & 15) * 8u; }
@@ -145,6 +159,10 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   const bool box = (args.flags & kFlagNormalize) != 0;
   const int RS = box ? 13 : 9;                                 // doubles per row: Σp(2) Σq(2) Σpqᵀ(4) Σ‖p−q‖² [+ lo(2) hi(2)]
   int* sh_fail = reinterpret_cast<int*>(smem + (size_t)Q * kQCtlBytes);
+  uint32_t* tickets = reinterpret_cast<uint32_t*>(smem + (size_t)Q * kQCtlBytes + 64);       // [16]
+  int32_t* states = reinterpret_cast<int32_t*>(smem + (size_t)Q * kQCtlBytes + 128);         // [16]
+  auto open_slot = [&](int q, int ntasks) { __hip_atomic_store(&tickets[q], (unsigned)ntasks << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto close_slot = [&](int q) { __hip_atomic_store(&tickets[q], kQClosed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   auto ctl_of = [&](int q) { return reinterpret_cast<QueueCtl*>(smem + (size_t)q * kQCtlBytes); };
   auto slot_of = [&](int q) { return smem + lay.ctl_bytes + (size_t)q * lay.slot_bytes; };
 #ifdef LSLAM_QUEUE_PROFILE
@@ -155,25 +173,22 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
 #define QUEUE_COUNT(k, v) do {} while (0)
 #endif
 
-  if (tid < Q) {
-    QueueCtl* c = ctl_of(tid);
-    c->state = 2; c->next_task = kQBusy; c->ntasks = 0; c->done_tasks = 0; c->problem = -1;
+  if (tid < 16) {
+    tickets[tid] = kQClosed;
+    states[tid] = tid < Q ? 2 : 0;
+    if (tid < Q) { QueueCtl* c = ctl_of(tid); c->done_tasks = 0; c->problem = -1; }
   }
   if (tid == 0) *sh_fail = 0;
   __syncthreads();                                             // the only barrier of the kernel
 
-  // Slabs per task of a problem with `nslabs` slabs in its iteration `it`: three (one reduction per three slabs) while the problem
-  // is young, as few as the 16 rows of partial sums allow from its 8th iteration on — the long problems are what a launch ends on,
-  // and then all waves should iterate the few that are left.  A function of the problem alone — not of the batch it came in, its
-  // place in it, or timing: the grouping of the partial sums, hence every bit of a pair's result, is the same wherever and
-  // whenever the pair is solved (tests/test_gpu_shard.py demands that).
-  auto task_size = [&](int nslabs, int it) -> int {
-    if (lay.G > 0) return lay.G;
-    const int gmin = (nslabs + kQRows - 1) / kQRows;
-    int G = it < 8 ? (gmin > 3 ? gmin : 3) : gmin;
-    if (G > nslabs) G = nslabs;
-    return G < 1 ? 1 : G;
-  };
+  // An iteration of a problem is two rounds of tasks.  SEARCH tasks (phase 0) cover Ga consecutive slabs each and leave the
+  // matches in LDS: small, so that a problem's waves finish together and a closing problem leaves few waves without work (the
+  // search is exact: its grouping cannot change a result).  MOMENT tasks (phase 1) cover kQMomentSlabs slabs each and leave one
+  // row of float64 partial sums: large, one cross-lane reduction per 1024 pairs; a LiDAR-sized problem has one, run by the wave
+  // that completed the last search task.  Row boundaries depend on the problem's size alone — not on the batch, the slot, or
+  // timing — so every bit of a pair's result is the same wherever and whenever the pair is solved (tests/test_gpu_shard.py).
+  auto search_group = [&](int nslabs) -> int { return lay.G > 0 ? lay.G : (nslabs > 32 ? 2 : 1); };
+  auto moment_tasks = [&](int nslabs) -> int { return nslabs > 0 ? (nslabs + kQMomentSlabs - 1) / kQMomentSlabs : 1; };
 
   // ---- one wave: draw the next problem and stage it into slot q (or mark the slot empty for good) ----
   auto refill = [&](int q) {
@@ -182,7 +197,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     if (lane == 0) p = (int)atomicAdd(&lay.queue[0], 1u);
     p = __builtin_amdgcn_readfirstlane(p);
     if (p >= S) {
-      if (lane == 0) __hip_atomic_store(&c->state, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // next_task stays kQBusy
+      if (lane == 0) __hip_atomic_store(&states[q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // the ticket stays closed
       return;
     }
     unsigned char* base = slot_of(q);
@@ -246,30 +261,28 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     }
     if constexpr (F64) { tmax = wave_max_dpp(tmax); smax = wave_max_dpp(smax); }
     if (lane < 16) c->T[lane] = args.init_T[(int64_t)16 * p + lane];
-    if (lane == 0) __hip_atomic_store(&c->state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const int G = task_size(nslabs, 0);
+    if (lane == 0) __hip_atomic_store(&states[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int G = search_group(nslabs);
     if (lane == 0) {
       StopState st0; stop_init(st0);
       c->stop = st0; c->err = 0.0;
       c->problem = p; c->n = n; c->m = m; c->nchunks = nchunks; c->nslabs = nslabs;
-      c->G = G; c->ntasks = nslabs > 0 ? (nslabs + G - 1) / G : 1;
+      c->G = G; c->phase = 0;
       c->done_tasks = 0;
       c->Rt = F64 ? sqrtf(tmax) * 1.0001f : 0.f;
       c->Rs = F64 ? sqrtf(smax) * 1.0001f : 0.f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_store(&c->next_task, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // open
+    if (lane == 0) open_slot(q, nslabs > 0 ? (nslabs + G - 1) / G : 1);
   };
 
   // ---- one wave: the slot's last task of this iteration is done — reduce, solve, stop rules; outputs and refill on convergence ----
   auto finish = [&](int q) {
     QueueCtl* c = ctl_of(q);
-    if (lane == 0) __hip_atomic_store(&c->next_task, kQBusy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     unsigned char* base = slot_of(q);
-    double* rows = reinterpret_cast<double*>(base + lay.rows_off);       // [rows_cap][RS] + 16 doubles of scratch
-    const int ntasks = lds_load_i32(&c->ntasks);
+    double* rows = reinterpret_cast<double*>(base + lay.rows_off);       // [kQRows][RS] + 16 doubles of scratch
     const int n = lds_load_i32(&c->n), nslabs = lds_load_i32(&c->nslabs);
+    const int ntasks = moment_tasks(nslabs);                   // rows of partial sums
     double col;
     {
       const int cl = lane < RS ? lane : 0;
@@ -311,13 +324,13 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     if (lane < 16) c->T[lane] = tn;
     QUEUE_MARK(2);
     if (!stop) {
-      const int G = task_size(nslabs, st.executed);
+      const int G = search_group(nslabs);
       if (lane == 0) {
         c->stop = st; c->err = err; c->done_tasks = 0;
-        c->G = G; c->ntasks = nslabs > 0 ? (nslabs + G - 1) / G : 1;
+        c->G = G; c->phase = 0;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) __hip_atomic_store(&c->next_task, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    // next iteration
+      if (lane == 0) open_slot(q, nslabs > 0 ? (nslabs + G - 1) / G : 1);                                    // next iteration
       return;
     }
     const int p = lds_load_i32(&c->problem);
@@ -333,29 +346,27 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     QUEUE_MARK(3);
   };
 
-  // ---- one wave: task t of slot q — G slabs of 64 sources: nearest neighbours, then their float64 moments ----
-  auto run_task = [&](int q, int t) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // ---- one wave: search task t of slot q — the nearest neighbours of G slabs of 64 sources, left in LDS ----
+  auto search_task = [&](int q, int t) {
     QueueCtl* c = ctl_of(q);
     unsigned char* base = slot_of(q);
     const float4* slab_box = reinterpret_cast<const float4*>(base + lay.slab_off);
-    const int2* tdelta = reinterpret_cast<const int2*>(base + lay.tdelta_off);
     const float2* sh_src = reinterpret_cast<const float2*>(base + lay.src_off);
     const double2* sh_src64 = reinterpret_cast<const double2*>(base + lay.src_off);
     uint16_t* sh_prev = reinterpret_cast<uint16_t*>(base + lay.prev_off);
-    double* rows = reinterpret_cast<double*>(base + lay.rows_off);
-    const int n = lds_load_i32(&c->n), m = lds_load_i32(&c->m), nchunks = lds_load_i32(&c->nchunks), nslabs = lds_load_i32(&c->nslabs);
-    const int ntasks = lds_load_i32(&c->ntasks), G = lds_load_i32(&c->G);
-    const int p = lds_load_i32(&c->problem);
+    const int cw = ctl_load(c, lane);
+    const int n = CTL_INT(cw, n), m = CTL_INT(cw, m), nchunks = CTL_INT(cw, nchunks), nslabs = CTL_INT(cw, nslabs);
+    const int G = CTL_INT(cw, G);
+    const int p = CTL_INT(cw, problem);
     double T[2][4];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) T[r][k] = wave_uniform(c->T[4 * r + k]);
+      for (int k = 0; k < 4; ++k) T[r][k] = CTL_T(cw, 4 * r + k);
     NearTie nt = near_tie_setup(false, 0.f, 0.f, 0.f);
     if constexpr (F64) {
-      const float Rt = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c->Rt)));
-      const float Rs = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c->Rs)));
+      const float Rt = CTL_FLOAT(cw, Rt);
+      const float Rs = CTL_FLOAT(cw, Rs);
       nt = near_tie_setup(true, Rt, Rs, sqrtf((float)(T[0][0] * T[0][0] + T[0][1] * T[0][1] + T[1][0] * T[1][0] + T[1][1] * T[1][1])) * 1.0001f);
     }
     // the bound a chunk must beat: the lane's best itself, or in float64-exact mode everything within its near-tie window;
@@ -534,18 +545,35 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       if (owns) sh_prev[i] = (uint16_t)pos;
     }
     QUEUE_MARK(0);
+  };
 
-    // ---- float64 moments of the task's matched pairs (kept apart from the search: the accumulators are not live while it runs)
+  // ---- one wave: row r of the slot's float64 partial sums — the matched pairs of slabs [r·kQMomentSlabs, …) --------------------
+  auto moment_task = [&](int q, int r) {
+    QueueCtl* c = ctl_of(q);
+    unsigned char* base = slot_of(q);
+    const int2* tdelta = reinterpret_cast<const int2*>(base + lay.tdelta_off);
+    const float2* sh_src = reinterpret_cast<const float2*>(base + lay.src_off);
+    const double2* sh_src64 = reinterpret_cast<const double2*>(base + lay.src_off);
+    const uint16_t* sh_prev = reinterpret_cast<const uint16_t*>(base + lay.prev_off);
+    double* rows = reinterpret_cast<double*>(base + lay.rows_off);
+    const int cw = ctl_load(c, lane);
+    const int n = CTL_INT(cw, n), nslabs = CTL_INT(cw, nslabs);
+    double T[2][4];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) T[rr][k] = CTL_T(cw, 4 * rr + k);
     double a[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) a[k] = 0.0;
     double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
+    const int slab_lo = r * kQMomentSlabs, slab_hi = min(slab_lo + kQMomentSlabs, nslabs);
     for (int slab = slab_lo; slab < slab_hi; ++slab) {
       const int i = slab * kWave + lane;
       if (i < n) {
         const int ps = sh_prev[i];
         double x, y, qx, qy;
-        const float2 qv = target_at(ps);
+        const float2 qv = *reinterpret_cast<const float2*>(base + rec_off(ps));
         if constexpr (F64) {
           const double2 sp = sh_src64[i];
           const int2 dv = tdelta[ps];
@@ -577,17 +605,38 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       for (int k = 0; k < 2; ++k) { lo[k] = wave_min_dpp_last(lo[k]); hi[k] = wave_max_dpp_last(hi[k]); }
     }
     if (lane == 63) {
-      double* row = rows + (size_t)t * RS;
+      double* row = rows + (size_t)r * RS;
 #pragma unroll
       for (int k = 0; k < 9; ++k) row[k] = a[k];
       if (box) { row[9] = lo[0]; row[10] = lo[1]; row[11] = hi[0]; row[12] = hi[1]; }
     }
     QUEUE_MARK(1);
+  };
+
+  // ---- one wave: task t of the slot's current round; the wave that completes the round's last task moves the problem on ---------
+  auto run_task = [&](int q, int t, int ntasks) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    QueueCtl* c = ctl_of(q);
+    const int phase = lds_load_i32(&c->phase);
+    if (phase == 0) search_task(q, t); else moment_task(q, t);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     unsigned d = 0;
     if (lane == 0) d = atomicAdd(&c->done_tasks, 1u) + 1u;
     d = __builtin_amdgcn_readfirstlane(d);
-    if (d == (unsigned)ntasks) finish(q);
+    if (d != (unsigned)ntasks) return;
+    if (lane == 0) close_slot(q);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (phase == 0) {
+      const int nrows = moment_tasks(lds_load_i32(&c->nslabs));
+      if (nrows > 1) {                                         // a large problem: its moments are a round of tasks as well
+        if (lane == 0) { c->phase = 1; c->done_tasks = 0; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) open_slot(q, nrows);
+        return;
+      }
+      moment_task(q, 0);
+    }
+    finish(q);
   };
 
   // ---- first problems, then the queue ----
@@ -596,27 +645,26 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   int pref = wave % Q;
   long long idle_since = -1;
   for (;;) {
-    bool got = false, alive = false;
-    for (int k = 0; k < Q; ++k) {
-      int q = pref + k;
-      if (q >= Q) q -= Q;
-      QueueCtl* c = ctl_of(q);
-      alive |= lds_load_i32(&c->state) != 0;
-      const unsigned nt_ = lds_load_u32(&c->next_task);
-      if (nt_ < (unsigned)lds_load_i32(&c->ntasks)) {
-        unsigned t = 0;
-        if (lane == 0) t = atomicAdd(&c->next_task, 1u);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (t < (unsigned)lds_load_i32(&c->ntasks)) {
-          QUEUE_MARK(4);
-          run_task(q, (int)t);
-          got = true; pref = q;
-          break;
-        }
+    // every slot's ticket with one load (lane q: slot q); the open slots as a ballot; the first one from `pref` on
+    const unsigned w = __hip_atomic_load(&tickets[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long open = __ballot(lane < Q && (w & 0xffffu) < (w >> 16));
+    if (open) {
+      const unsigned long long from_pref = open >> pref;
+      const int q = from_pref ? pref + __builtin_ctzll(from_pref) : __builtin_ctzll(open);
+      unsigned old = 0;
+      if (lane == 0) old = atomicAdd(&tickets[q], 1u);
+      old = __builtin_amdgcn_readfirstlane(old);
+      const unsigned t = old & 0xffffu, ntasks = old >> 16;
+      if (t < ntasks) {
+        QUEUE_MARK(4);
+        run_task(q, (int)t, (int)ntasks);
+        pref = q;
+        idle_since = -1;
       }
+      continue;
     }
-    if (got) { idle_since = -1; continue; }
-    if (!alive) break;
+    const int st_ = __hip_atomic_load(&states[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (!__any(lane < Q && st_ != 0)) break;
     if (lds_load_i32(sh_fail)) break;
     const long long now = (long long)wall_clock64();
     if (idle_since < 0) idle_since = now;
@@ -625,6 +673,9 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       break;
     }
     __builtin_amdgcn_s_sleep(2);
+#ifdef LSLAM_QUEUE_PROFILE
+    if (__any(lane < Q && st_ == 0)) QUEUE_MARK(5); else QUEUE_MARK(4);       // [5]: idle while the workgroup's slots are draining (the queue is exhausted)
+#endif
   }
   QUEUE_MARK(4);
 #ifdef LSLAM_QUEUE_PROFILE
@@ -675,7 +726,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   int W = env_int("LSLAM_ICP_QUEUE_WAVES", 16);
   if (W < 1 || W > kIcpBatchMaxWaves) W = 16;
   int Q = 1;
-  while (Q < 16 && (size_t)(Q + 1) * kQCtlBytes + 64 + (size_t)(Q + 1) * slot <= kLdsPerCu) ++Q;
+  while (Q < 16 && (size_t)(Q + 1) * kQCtlBytes + 192 + (size_t)(Q + 1) * slot <= kLdsPerCu) ++Q;
   {
     // fewer problems than the chip has slots: spread them over the CUs
     const int64_t slots_needed = ((int64_t)S + cus - 1) / cus;
@@ -685,10 +736,10 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   }
   if (Q * (nslabs > 0 ? nslabs : 1) < W) W = Q * (nslabs > 0 ? nslabs : 1);      // no more waves than tasks can ever be open
   lay.slot_bytes = (uint32_t)slot;
-  lay.ctl_bytes = (uint32_t)up((size_t)Q * kQCtlBytes + 64);
+  lay.ctl_bytes = (uint32_t)up((size_t)Q * kQCtlBytes + 64 + 128);
   lay.Q = Q;
-  lay.G = env_int("LSLAM_ICP_QUEUE_G", 0);                     // 0: chosen per problem and iteration (task_size)
-  if (lay.G > 0 && (nslabs + lay.G - 1) / lay.G > rows_cap) lay.G = (nslabs + rows_cap - 1) / rows_cap;
+  lay.G = env_int("LSLAM_ICP_QUEUE_G", 0);                     // slabs per search task; 0: one, two for problems above 32 slabs
+  if (nslabs > kQRows * kQMomentSlabs) return hipErrorInvalidValue;
   lay.queue = sc.queue;
   lay.debug = getenv("LSLAM_DEBUG") ? 1 : 0;
   const size_t smem = lay.ctl_bytes + (size_t)Q * slot;
@@ -704,8 +755,8 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
     fprintf(stderr, "[lslam] queue kernel, previous launch: problems drawn %u, timeouts %u, tie passes %u\n", hu[0], hu[1], hu[2]);
 #ifdef LSLAM_QUEUE_PROFILE
     double tot = 0; for (int k = 0; k < 6; ++k) tot += (double)h[2 + k];
-    if (tot > 0) fprintf(stderr, "[lslam] queue kernel, share of wave cycles: search %.3f  moments %.3f  reduce+solve %.3f  outputs+staging %.3f  idle %.3f\n",
-                         h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot);
+    if (tot > 0) fprintf(stderr, "[lslam] queue kernel, share of wave cycles: search %.3f  moments %.3f  reduce+solve %.3f  outputs+staging %.3f  idle %.3f  idle while draining %.3f\n",
+                         h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot, h[7] / tot);
     if (h[8] > 0) fprintf(stderr, "[lslam] queue kernel, per slab searched: %.2f surviving boxes, %.2f list rounds, %.2f (point, chunk) entries; %.0f cycles per slab\n",
                           (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], tot / h[8]);
 #endif
