@@ -22,6 +22,14 @@
 // exhausted, which every problem reaches through max_iters at the latest; idle waves poll with s_sleep and give up after
 // kQTimeoutTicks of wall clock without any task (a can't-happen guard: the grid must always drain).
 //
+// Iterations after the first do not search every source again.  A search leaves, per source, a MARGIN: half the gap between
+// its nearest target and a proven lower bound on the distance to every other target (the second smallest distance evaluated, and
+// the reach beyond which chunks were skipped — extended by E for that purpose), minus the rounding of the positions.  Every later
+// iteration subtracts a bound on how far the new transform moved the source (‖ΔR‖_F·|p|max + |Δt| of its slab); while the margin
+// stays positive the nearest target cannot have changed — by the triangle inequality, with the float32 recipe's rounding and in
+// float64-exact mode the near-tie window inside the margin — and the source keeps its match.  The sources of a task whose margin
+// ran out are gathered, 64 at a time, and searched as before.  Exactness is untouched: a source is skipped only on a proof.
+//
 // LDS record of a chunk: its 16 targets (128 B) followed by its box (16 B) — 144 B.  A lane that compares its point with a
 // chunk reads eight 16-byte pairs at IMMEDIATE offsets from one address register (no per-target address arithmetic); lanes on
 // different chunks fall on the same banks only when their chunk ids agree modulo 16, and the 64 boxes of a ballot group are a
@@ -49,8 +57,8 @@ namespace lslam {
 constexpr int kQCtlBytes = 256;
 constexpr long long kQTimeoutTicks = 400000000ll;      // 4 s of the 100 MHz wall clock
 constexpr int kQRec = kPruneChunk * 8 + 16;            // bytes per chunk record: 16 targets + the chunk's box
-constexpr int kQMomentSlabs = 16;                      // slabs of 64 pairs per row of float64 partial sums
-constexpr int kQRows = 8;                              // rows per slot: problems of up to 8192 sources
+constexpr int kQRows = 8;                              // rows of float64 partial sums per slot (moment_slabs: one row up to 20 slabs, 8 slabs per row up to 64, 16 up to 128)
+constexpr float kQExtend = 4.f;                        // E = kQExtend × the last step's largest displacement (capped): what a search pays for later certificates
 constexpr float kQPad = 1.0e18f;                       // x of the padding targets (times 1 + slot/16), y = 0
 constexpr float kQFarD2 = 1.0e35f;                     // a best distance beyond this is not trusted (padding, overflow): exhaustive pass
 static_assert(kPruneChunk == 16, "the chunk record and the pair loop are written for 16 targets per chunk");
@@ -60,9 +68,12 @@ struct QueueCtl {                                      // one per slot, in LDS; 
   double err;
   StopState stop;
   int32_t problem;
-  int32_t n, m, nchunks, nslabs, G, phase;             // phase 0: search tasks of G slabs, 1: moment tasks of kQMomentSlabs slabs
+  int32_t n, m, nchunks, nslabs, G, phase;             // phase 0: search tasks of G slabs, 1: moment tasks of moment_slabs() slabs
   uint32_t done_tasks;                                 // tasks completed in this round
-  float Rt, Rs;                                        // float64-exact mode: largest |t|, |p| of the problem
+  float Rt, Rs;                                        // largest |t|, |p| of the problem
+  float stepR, stepT;                                  // ‖R_k − R_{k−1}‖_F and |t_k − t_{k−1}| of the transform the current iteration searches with (rounded up)
+  float extend;                                        // E of the current iteration's searches
+  float ecap;                                          // cap of E for this problem
 };
 static_assert(sizeof(QueueCtl) <= kQCtlBytes, "control block");
 #define QCTL_DWORD(field) (int)(offsetof(QueueCtl, field) / 4)
@@ -97,17 +108,32 @@ __device__ __forceinline__ int ctl_load(const QueueCtl* c, int lane) {
 #define CTL_FLOAT(cw, field) __int_as_float(__builtin_amdgcn_readlane(cw, QCTL_DWORD(field)))
 #define CTL_T(cw, k) __hiloint2double(__builtin_amdgcn_readlane(cw, 2 * (k) + 1), __builtin_amdgcn_readlane(cw, 2 * (k)))
 
+// A float32 source from its LDS copy or, where a slot has no room for one, from the sorted copy in memory — as two explicit
+// paths: written as one conditional expression the compiler selects between the two POINTERS and emits a flat_load (the slow
+// path for an LDS address, and a wait on both memory counters).  The empty asm keeps the paths apart.
+__device__ __forceinline__ float2 load_source(bool in_lds, const float2* lds, const float2* mem, int i) {
+  float2 v;
+  if (in_lds) {
+    v = lds[i];
+  } else {
+    v = mem[i];
+    asm volatile("" : "+v"(v.x), "+v"(v.y));
+  }
+  return v;
+}
+
 // byte offset of sorted target j inside a slot's records
 __device__ __forceinline__ unsigned rec_off(int j) { return (unsigned)(j >> 4) * kQRec + (unsigned)(j & 15) * 8u; }
 
 // One chunk against ONE point of this lane (a gather: every lane its own chunk), all eight pair reads in flight before the
 // first distance.  bd / pos: the smallest distance so far and the sorted position of its target.
-//   float32 mode: a pair's nearer target enters one compare against the best; `sec` records the VALUE at the last event "a
-//   distance equals the best so far" or "both distances of a pair are equal and take the lead".  The best only decreases, so
-//   after the search sec == bd exactly when two targets share the final minimum (decided by the pass over equal distances).
-//   float64-exact mode: the second smallest distance over everything evaluated is tracked (v_med3), the near-tie window needs it.
-template <bool F64>
-__device__ __forceinline__ void queue_eval_chunk(unsigned tile0, int chunk, float x, float y, float& bd, float& sec, int& pos, bool& tie) {
+// TRACK: sec is the second smallest distance over everything evaluated for the point (v_med3) — inside the near-tie window ⇔ float64
+//   must decide (float64-exact mode), equal to bd ⇔ two targets share the minimum, and every later certificate rests on it.
+// !TRACK (float32 mode without certificates): a pair's nearer target enters one compare against the best, and sec only records the
+//   VALUE at the last event "a distance equals the best so far" or "both distances of a pair are equal and take the lead".  The
+//   best only decreases, so after the search sec == bd exactly when two targets share the final minimum.
+template <bool TRACK>
+__device__ __forceinline__ void queue_eval_chunk(unsigned tile0, int chunk, float x, float y, float& bd, float& sec, int& pos) {
   typedef float __attribute__((ext_vector_type(4))) Vec4;
   typedef const __attribute__((address_space(3))) Vec4* LdsPair;
   const unsigned rec = tile0 + (unsigned)chunk * kQRec;
@@ -120,7 +146,7 @@ __device__ __forceinline__ void queue_eval_chunk(unsigned tile0, int chunk, floa
   for (int c = 0; c < 8; ++c) {
     const float d0 = dist2(x, y, v[c].x, v[c].y);
     const float d1 = dist2(x, y, v[c].z, v[c].w);
-    if constexpr (F64) {
+    if constexpr (TRACK) {
       const bool lt0 = d0 < bd;
       sec = __builtin_amdgcn_fmed3f(bd, sec, d0);
       kb = lt0 ? 2 * c : kb;
@@ -149,7 +175,8 @@ __device__ __forceinline__ void queue_eval_chunk(unsigned tile0, int chunk, floa
 #define QUEUE_MARK(k) do {} while (0)
 #endif
 
-template <bool F64>
+// CERT: sources keep their match on a proof (margins; see the header) instead of being searched in every iteration
+template <bool F64, bool CERT>
 __global__ void __launch_bounds__(kIcpBatchMaxThreads, 4)      // ≤ 128 VGPRs: one workgroup of up to 16 waves per CU (the VALU is saturated by four waves per SIMD: tools/queue_stats.sh)
 icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   constexpr int CHUNK = kPruneChunk;
@@ -167,7 +194,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   auto slot_of = [&](int q) { return smem + lay.ctl_bytes + (size_t)q * lay.slot_bytes; };
 #ifdef LSLAM_QUEUE_PROFILE
   unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime();
-  unsigned long long cnt[4] = {0, 0, 0, 0};                   // slabs searched, surviving boxes, list rounds, (point, chunk) list entries
+  unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};             // searches of ≤ 64 sources, surviving boxes, list rounds, (point, chunk) list entries, sources visited, sources searched
 #define QUEUE_COUNT(k, v) do { cnt[k] += (v); } while (0)
 #else
 #define QUEUE_COUNT(k, v) do {} while (0)
@@ -183,12 +210,22 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
 
   // An iteration of a problem is two rounds of tasks.  SEARCH tasks (phase 0) cover Ga consecutive slabs each and leave the
   // matches in LDS: small, so that a problem's waves finish together and a closing problem leaves few waves without work (the
-  // search is exact: its grouping cannot change a result).  MOMENT tasks (phase 1) cover kQMomentSlabs slabs each and leave one
-  // row of float64 partial sums: large, one cross-lane reduction per 1024 pairs; a LiDAR-sized problem has one, run by the wave
-  // that completed the last search task.  Row boundaries depend on the problem's size alone — not on the batch, the slot, or
+  // search is exact: its grouping cannot change a result).  MOMENT tasks (phase 1) cover moment_slabs() slabs each and leave one
+  // row of float64 partial sums: large, one cross-lane reduction per 512 pairs or more; a LiDAR-sized problem (up to 1280 sources)
+  // has one, run by the wave that completed the last search task.  Row boundaries depend on the problem's size alone — not on the batch, the slot, or
   // timing — so every bit of a pair's result is the same wherever and whenever the pair is solved (tests/test_gpu_shard.py).
-  auto search_group = [&](int nslabs) -> int { return lay.G > 0 ? lay.G : (nslabs > 32 ? 2 : 1); };
-  auto moment_tasks = [&](int nslabs) -> int { return nslabs > 0 ? (nslabs + kQMomentSlabs - 1) / kQMomentSlabs : 1; };
+  // (first iteration: every source is searched — one or two slabs per task; later most keep their match and a task gathers the rest
+  // of four or eight slabs into full waves)
+  auto search_group = [&](int nslabs, int it) -> int {
+    if (lay.G > 0) return lay.G;
+    if (it == 0 || !CERT) return nslabs > 32 ? 2 : 1;
+    return nslabs > 32 ? 8 : 4;
+  };
+#ifndef QEXP_MOM
+#define QEXP_MOM 20
+#endif
+  auto moment_slabs = [&](int nslabs) -> int { return nslabs <= QEXP_MOM ? (nslabs > 0 ? nslabs : 1) : (nslabs <= 64 ? 8 : 16); };
+  auto moment_tasks = [&](int nslabs) -> int { return nslabs > 0 ? (nslabs + moment_slabs(nslabs) - 1) / moment_slabs(nslabs) : 1; };
 
   // ---- one wave: draw the next problem and stage it into slot q (or mark the slot empty for good) ----
   auto refill = [&](int q) {
@@ -201,39 +238,69 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       return;
     }
     unsigned char* base = slot_of(q);
-    float4* slab_box = reinterpret_cast<float4*>(base + lay.slab_off);
+    float* slab_pmax = reinterpret_cast<float*>(base + lay.slab_off);
     int2* tdelta = reinterpret_cast<int2*>(base + lay.tdelta_off);
     float2* sh_src = reinterpret_cast<float2*>(base + lay.src_off);
     double2* sh_src64 = reinterpret_cast<double2*>(base + lay.src_off);
     uint16_t* sh_prev = reinterpret_cast<uint16_t*>(base + lay.prev_off);
+    uint16_t* sh_margin = reinterpret_cast<uint16_t*>(base + lay.margin_off);
+    const bool src_lds = lay.src_off != 0xffffffffu;
     const int64_t s0 = args.src_off[p], t0 = args.tgt_off[p];
     const int n = (int)(args.src_off[p + 1] - s0), m = (int)(args.tgt_off[p + 1] - t0);
     const int64_t ss = (int64_t)p * sc.src_stride, ts = (int64_t)p * sc.tgt_stride;
     const int nchunks = (m + CHUNK - 1) / CHUNK, nslabs = (n + kWave - 1) / kWave;
     float tmax = 0.f, smax = 0.f;
+    float bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;      // the target's box
     for (int j = lane; j < nchunks * CHUNK; j += kWave) {
       const float2 v = (j < m) ? sc.tgt_sorted[ts + j] : make_float2(kQPad * (1.f + 0.0625f * (float)(j & 15)), 0.f);
       *reinterpret_cast<float2*>(base + rec_off(j)) = v;
+      if ((F64 || CERT) && j < m) {
+        tmax = fmaxf(tmax, __builtin_fmaf(v.y, v.y, v.x * v.x));
+        if constexpr (CERT) { bx0 = fminf(bx0, v.x); by0 = fminf(by0, v.y); bx1 = fmaxf(bx1, v.x); by1 = fmaxf(by1, v.y); }
+      }
       if constexpr (F64) {
         int2 d = make_int2(0, 0);
         if (j < m) {
-          tmax = fmaxf(tmax, __builtin_fmaf(v.y, v.y, v.x * v.x));
           const double2 td = sc.tgt64_sorted[ts + j];
           d = make_int2(residual_count(td.x, v.x), residual_count(td.y, v.y));
         }
         tdelta[j] = d;
       }
     }
-    for (int i = lane; i < n; i += kWave) {
+    // sources (all loads in flight before the first use), no matches and no margins yet
+    for (int i0 = 0; i0 < n; i0 += 8 * kWave) {
       if constexpr (F64) {
-        const double2 pd = sc.src64_sorted[ss + i];
-        sh_src64[i] = pd;
-        const float vx = (float)pd.x, vy = (float)pd.y;
-        smax = fmaxf(smax, __builtin_fmaf(vy, vy, vx * vx));
-      } else {
-        sh_src[i] = sc.src_sorted[ss + i];
+        double2 pd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * kWave + lane; pd[u] = i < n ? sc.src64_sorted[ss + i] : make_double2(0.0, 0.0); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * kWave + lane; if (i < n) sh_src64[i] = pd[u]; }
+      } else if (src_lds) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * kWave + lane; v[u] = i < n ? sc.src_sorted[ss + i] : make_float2(0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * kWave + lane; if (i < n) sh_src[i] = v[u]; }
       }
+    }
+    for (int i = lane; i < n; i += kWave) {
       sh_prev[i] = 0xffff;
+      if constexpr (CERT) sh_margin[i] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // the largest |p| of every slab of 64 sources: what a change of the transform can move them by
+    for (int sl = 0; (F64 || CERT) && sl < nslabs; ++sl) {
+      const int i = sl * kWave + lane;
+      float p2 = 0.f;
+      if (i < n) {
+        float vx, vy;
+        if constexpr (F64) { const double2 pd = sh_src64[i]; vx = (float)pd.x; vy = (float)pd.y; }
+        else { const float2 v = load_source(src_lds, sh_src, sc.src_sorted + ss, i); vx = v.x; vy = v.y; }
+        p2 = __builtin_fmaf(vy, vy, vx * vx);
+      }
+      p2 = wave_max_dpp(p2);
+      smax = fmaxf(smax, p2);
+      if (lane == 0) slab_pmax[sl] = sqrtf(p2) * 1.000001f + 1e-30f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     for (int cidx = lane; cidx < nchunks; cidx += kWave) {     // boxes over the real points only
@@ -245,32 +312,24 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       }
       *reinterpret_cast<float4*>(base + (size_t)cidx * kQRec + CHUNK * 8) = make_float4(x0, y0, x1, y1);
     }
-    // the box of every slab of 64 consecutive sources in the sources' own frame (lslam_icp_pruned.hip: per iteration the wave's
-    // box is this box under T)
-    for (int sl = 0; sl < nslabs; ++sl) {
-      const int i = sl * kWave + lane;
-      float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
-      if (i < n) {
-        float2 v;
-        if constexpr (F64) { const double2 pd = sh_src64[i]; v = make_float2((float)pd.x, (float)pd.y); }
-        else v = sh_src[i];
-        x0 = v.x; y0 = v.y; x1 = v.x; y1 = v.y;
-      }
-      x0 = wave_min_dpp(x0); y0 = wave_min_dpp(y0); x1 = wave_max_dpp(x1); y1 = wave_max_dpp(y1);
-      if (lane == 0) slab_box[sl] = make_float4(x0, y0, x1, y1);
-    }
-    if constexpr (F64) { tmax = wave_max_dpp(tmax); smax = wave_max_dpp(smax); }
+    if constexpr (F64 || CERT) tmax = wave_max_dpp(tmax);
+    if constexpr (CERT) { bx0 = wave_min_dpp(bx0); by0 = wave_min_dpp(by0); bx1 = wave_max_dpp(bx1); by1 = wave_max_dpp(by1); }
     if (lane < 16) c->T[lane] = args.init_T[(int64_t)16 * p + lane];
     if (lane == 0) __hip_atomic_store(&states[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const int G = search_group(nslabs);
+    const int G = search_group(nslabs, 0);
     if (lane == 0) {
       StopState st0; stop_init(st0);
       c->stop = st0; c->err = 0.0;
       c->problem = p; c->n = n; c->m = m; c->nchunks = nchunks; c->nslabs = nslabs;
       c->G = G; c->phase = 0;
       c->done_tasks = 0;
-      c->Rt = F64 ? sqrtf(tmax) * 1.0001f : 0.f;
-      c->Rs = F64 ? sqrtf(smax) * 1.0001f : 0.f;
+      c->Rt = sqrtf(tmax) * 1.0001f;
+      c->Rs = sqrtf(smax) * 1.0001f;
+      c->stepR = INFINITY; c->stepT = INFINITY;               // no earlier transform: nothing is certified in the first iteration
+      c->extend = 0.f;
+      // E is capped at a fraction of the targets' mean spacing (what the extended reach costs grows with E / spacing)
+      const float area = CERT ? fmaxf(bx1 - bx0, 0.f) * fmaxf(by1 - by0, 0.f) : 0.f;
+      c->ecap = CERT ? lay.ecap_frac * sqrtf(area / (float)(m > 0 ? m : 1)) : 0.f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) open_slot(q, nslabs > 0 ? (nslabs + G - 1) / G : 1);
@@ -317,17 +376,32 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     if (box) { mo.lo[0] = tot[9]; mo.lo[1] = tot[10]; mo.hi[0] = tot[11]; mo.hi[1] = tot[12]; }
     double R[9], pb[3], qb[3];
     step_parts(mo, true, R, pb, qb);
+    const double told = c->T[lane & 15];
     const double tn = step_times_prev_lane(R, pb, qb, c->T, rows + (size_t)kQRows * RS, lane);   // element `lane` of T_step·T_prev
+    // how far the new transform can move a source: ‖ΔR‖_F·|p| + |Δt| (Frobenius ≥ spectral norm), rounded up
+    float stepR = INFINITY, stepT = INFINITY;
+    if constexpr (CERT) {
+      const double dl = tn - told;
+      auto at = [&](int k) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dl), k), __builtin_amdgcn_readlane(__double2loint(dl), k)); };
+      const double d00 = at(0), d01 = at(1), d03 = at(3), d10 = at(4), d11 = at(5), d13 = at(7);
+      stepR = (float)(sqrt(d00 * d00 + d01 * d01 + d10 * d10 + d11 * d11) * 1.000001) + 1e-30f;
+      stepT = (float)(sqrt(d03 * d03 + d13 * d13) * 1.000001) + 1e-30f;
+    }
     const double err = error_from_moments(mo, box);
     StopState st = c->stop;
     const bool stop = stop_after_iteration(st, err, args.epsilon, args.stopping_thresh, args.max_iters);
     if (lane < 16) c->T[lane] = tn;
     QUEUE_MARK(2);
     if (!stop) {
-      const int G = search_group(nslabs);
+      const int G = search_group(nslabs, st.executed);
       if (lane == 0) {
         c->stop = st; c->err = err; c->done_tasks = 0;
         c->G = G; c->phase = 0;
+        c->stepR = stepR; c->stepT = stepT;
+        // the next searches extend their reach by E ≈ kQExtend × this step (the steps of a converging run shrink geometrically:
+        // margins of E / 2 then outlast what is still to come); nothing while the steps exceed what E may cost
+        const float moved = stepR * c->Rs + stepT, cap = c->ecap;
+        c->extend = CERT ? (kQExtend * moved <= cap ? kQExtend * moved : (moved <= cap ? cap : 0.f)) : 0.f;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) open_slot(q, nslabs > 0 ? (nslabs + G - 1) / G : 1);                                    // next iteration
@@ -350,14 +424,19 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   auto search_task = [&](int q, int t) {
     QueueCtl* c = ctl_of(q);
     unsigned char* base = slot_of(q);
-    const float4* slab_box = reinterpret_cast<const float4*>(base + lay.slab_off);
+    const float* slab_pmax = reinterpret_cast<const float*>(base + lay.slab_off);
     const float2* sh_src = reinterpret_cast<const float2*>(base + lay.src_off);
     const double2* sh_src64 = reinterpret_cast<const double2*>(base + lay.src_off);
     uint16_t* sh_prev = reinterpret_cast<uint16_t*>(base + lay.prev_off);
+    uint16_t* sh_margin = reinterpret_cast<uint16_t*>(base + lay.margin_off);
+    uint16_t* gathered = reinterpret_cast<uint16_t*>(smem + (size_t)Q * kQCtlBytes + 192) + wave * kWave;      // this wave's list of sources to search
+    const bool src_lds = lay.src_off != 0xffffffffu;
     const int cw = ctl_load(c, lane);
     const int n = CTL_INT(cw, n), m = CTL_INT(cw, m), nchunks = CTL_INT(cw, nchunks), nslabs = CTL_INT(cw, nslabs);
     const int G = CTL_INT(cw, G);
     const int p = CTL_INT(cw, problem);
+    const float stepR = CERT ? CTL_FLOAT(cw, stepR) : INFINITY, stepT = CERT ? CTL_FLOAT(cw, stepT) : INFINITY, extend = CERT ? CTL_FLOAT(cw, extend) : 0.f;
+    const float2* __restrict__ gsrc = sc.src_sorted + (int64_t)p * sc.src_stride;
     double T[2][4];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -380,32 +459,21 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     auto target_at = [&](int j) { return *reinterpret_cast<const float2*>(base + rec_off(j)); };
     auto box_at = [&](int cidx) { return *reinterpret_cast<const float4*>(base + (size_t)cidx * kQRec + CHUNK * 8); };
 
-    const int slab_lo = t * G, slab_hi = min(slab_lo + G, nslabs);
-    for (int slab = slab_lo; slab < slab_hi; ++slab) {
-      const int i = slab * kWave + lane;
-      const bool owns = i < n;
+    // ---- the nearest neighbours of up to 64 sources, one per lane (i: the lane's source, owns: it has one): exact search, then
+    // the source's margin for the iterations to come
+    auto search_points = [&](int i, bool owns) {
       QUEUE_COUNT(0, 1);
       float ax = 0.f, ay = 0.f;
       if (owns) {
         float2 v;
         if constexpr (F64) { const double2 pd = sh_src64[i]; v = make_float2((float)pd.x, (float)pd.y); }
-        else v = sh_src[i];
+        else v = load_source(src_lds, sh_src, gsrc, i);
         ax = (float)(T[0][0] * (double)v.x + T[0][1] * (double)v.y + T[0][3]);      // icp.py:116
         ay = (float)(T[1][0] * (double)v.x + T[1][1] * (double)v.y + T[1][3]);
       }
-      // the wave's box: the slab's box under T, widened by 16 ulps of the magnitudes involved (lslam_icp_pruned.hip)
-      float wx0, wy0, wx1, wy1;
-      {
-        const float4 sb = slab_box[slab];
-        const float r00 = (float)T[0][0], r01 = (float)T[0][1], r03 = (float)T[0][3], r10 = (float)T[1][0], r11 = (float)T[1][1], r13 = (float)T[1][3];
-        const float mx = fmaxf(fabsf(sb.x), fabsf(sb.z)), my = fmaxf(fabsf(sb.y), fabsf(sb.w));
-        const float ex = 1e-6f * (fabsf(r00) * mx + fabsf(r01) * my + fabsf(r03)) + 1e-30f;
-        const float ey = 1e-6f * (fabsf(r10) * mx + fabsf(r11) * my + fabsf(r13)) + 1e-30f;
-        wx0 = r03 + fminf(r00 * sb.x, r00 * sb.z) + fminf(r01 * sb.y, r01 * sb.w) - ex;
-        wx1 = r03 + fmaxf(r00 * sb.x, r00 * sb.z) + fmaxf(r01 * sb.y, r01 * sb.w) + ex;
-        wy0 = r13 + fminf(r10 * sb.x, r10 * sb.z) + fminf(r11 * sb.y, r11 * sb.w) - ey;
-        wy1 = r13 + fmaxf(r10 * sb.x, r10 * sb.z) + fmaxf(r11 * sb.y, r11 * sb.w) + ey;
-      }
+      // the wave's box: the box of its transformed points
+      const float wx0 = wave_min_dpp(owns ? ax : INFINITY), wy0 = wave_min_dpp(owns ? ay : INFINITY);
+      const float wx1 = wave_max_dpp(owns ? ax : -INFINITY), wy1 = wave_max_dpp(owns ? ay : -INFINITY);
       // ---- seed: the chunk of last iteration's match (first iteration: of the target at the same relative rank), compared
       // target by target by the lane itself: an exact bound before any box test
       float bd = owns ? INFINITY : -INFINITY;                  // lanes without a point never ask for a chunk
@@ -415,9 +483,13 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       if (owns) {
         const int pv = sh_prev[i];
         own = (pv != 0xffff ? pv : (int)(((long long)i * m) / n)) / CHUNK;
-        queue_eval_chunk<F64>(tile0, own, ax, ay, bd, sec, pos, tie);
+        queue_eval_chunk<F64 || CERT>(tile0, own, ax, ay, bd, sec, pos);
       }
-      const float wb = reach(wave_max_dpp(bd));                // no lane can ask for a chunk farther than this from the wave's box
+      // Every chunk whose box lies within the seed's distance + E of the point is compared: the nearest target is among them (E = 0
+      // would do for that), and what is skipped is farther than that distance + E — the second lower bound of the margin below.
+      const float dseed = CERT ? (owns ? sqrtf(bd) * 1.000001f + extend : -INFINITY) : 0.f;
+      const float rb = CERT ? reach(dseed * dseed * 1.000001f) : reach(bd);      // (−inf)² = +inf: lanes without a point are excluded by `owns` below
+      const float wb = wave_max_dpp(owns ? rb : -INFINITY);    // no lane can ask for a chunk farther than this from the wave's box
       // ---- sweep: 64 chunk boxes tested at once, one per lane, against the wave's box; the survivors against every lane's own
       // point and current bound → a 64-bit list per lane, which the lane works through
       for (int c0 = 0; c0 < nchunks; c0 += 64) {
@@ -432,7 +504,6 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         if (!todo) continue;
         QUEUE_COUNT(1, __builtin_popcountll(todo));
         unsigned list_lo = 0u, list_hi = 0u;
-        const float rb = reach(bd);                            // the seed's bound: a chunk evaluated later can only lower it
         while (todo) {
           // four surviving boxes per trip, their (wave-uniform) reads issued together: one LDS round trip per box, each waited for
           // in turn, was the longest dependent chain of the search
@@ -451,7 +522,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
           for (int u = 0; u < 4; ++u) {
             const float ox = fmaxf(fmaxf(b[u].x - ax, ax - b[u].z), 0.f);
             const float oy = fmaxf(fmaxf(b[u].y - ay, ay - b[u].w), 0.f);
-            const bool need = ok[u] && rb >= __builtin_fmaf(oy, oy, ox * ox);
+            const bool need = ok[u] && owns && rb >= __builtin_fmaf(oy, oy, ox * ox);
             // the bit's half is wave-uniform: one select and one or
             const unsigned bit = need ? (1u << (tb[u] & 31)) : 0u;
             if (tb[u] < 32) list_lo |= bit; else list_hi |= bit;
@@ -475,7 +546,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
           if (list != 0ull) {
             const int tbit = __builtin_ctzll(list);
             list &= list - 1;
-            queue_eval_chunk<F64>(tile0, c0 + tbit, ax, ay, bd, sec, pos, tie);
+            queue_eval_chunk<F64 || CERT>(tile0, c0 + tbit, ax, ay, bd, sec, pos);
           }
         }
       }
@@ -542,12 +613,70 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
           }
         }
       }
-      if (owns) sh_prev[i] = (uint16_t)pos;
+      if (owns) {
+        sh_prev[i] = (uint16_t)pos;
+        // The margin.  Real distances: nearest d1 ≤ √bd·(1+3u); every other target is at least L = min(√sec, √bd_seed + E)·(1−3u)
+        // away (evaluated ones: sec; skipped chunks: their boxes were farther than the reach).  After the source has moved by δ
+        // its nearest target is still the only one that the float32 recipe (relative error 4u) — and in float64-exact mode the
+        // near-tie window, 2ε = 2(ε0 + 6e-8·d) wide — can rank first as long as  L − δ > (d1 + δ)(1 + 1e-5) + 2ε0:  margin =
+        // (L − d1(1 + 2e-5))/2 − ε0 against δ(1 + 2e-5), less the rounding of the two float32 positions (2u|a|).  No margin after
+        // a tie pass (the minimum is shared or was undecided).
+        float mg = 0.f;
+        if (CERT && !tie && bd < kQFarD2) {
+          const float d1 = sqrtf(bd) * 1.00002f;
+          const float L = fminf(sqrtf(sec), dseed) * 0.99999f;
+          const float an = sqrtf(__builtin_fmaf(ay, ay, ax * ax));
+          float slack = 2.5e-7f * an + 1e-30f;
+          if constexpr (F64) slack += nt.eps0 * 1.01f;          // (the distance-proportional part of ε is inside the factors on d1 and on the step)
+          mg = 0.5f * (L - d1) - slack;
+        }
+        if constexpr (CERT) {                                    // kept as a half, rounded toward zero (never up)
+          const unsigned hb = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(mg > 0.f ? mg : 0.f, 0.f));
+          sh_margin[i] = (uint16_t)(hb & 0xffffu);
+        }
+      }
+    };
+
+    // ---- the task's slabs: sources whose margin outlasts this iteration's step keep their match; the others are gathered and
+    // searched 64 at a time (the first iteration, and any iteration without margins, searches slab by slab)
+    const int slab_lo = t * G, slab_hi = min(slab_lo + G, nslabs);
+    if constexpr (!CERT) {
+      for (int slab = slab_lo; slab < slab_hi; ++slab) search_points(slab * kWave + lane, slab * kWave + lane < n);
+      QUEUE_MARK(0);
+      return;
+    }
+    int pending = 0;                                           // entries of `gathered`
+    for (int slab = slab_lo; slab <= slab_hi; ++slab) {       // slab_hi: the trip that searches what is left in the list
+      const int i = slab * kWave + lane;
+      const bool owns = slab < slab_hi && i < n;
+      bool need = owns;
+      if (CERT && stepR < INFINITY && slab < slab_hi) {
+        const float step = (__builtin_fmaf(stepR, slab_pmax[slab], stepT)) * 1.00002f;
+        if (owns) {
+          const float left = (float)__builtin_bit_cast(_Float16, sh_margin[i]) - step;
+          need = !(left > 0.f);
+          if (!need) {
+            const unsigned hb = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(left, 0.f));
+            sh_margin[i] = (uint16_t)(hb & 0xffffu);
+          }
+        }
+      }
+      const unsigned long long mask = __ballot(need);
+      const int nneed = __builtin_popcountll(mask);
+      QUEUE_COUNT(4, __builtin_popcountll(__ballot(owns)));
+      QUEUE_COUNT(5, nneed);
+      if (pending > 0 && (slab == slab_hi || pending + nneed > kWave)) {      // the list is full, or this was the last slab
+        const int gi = lane < pending ? gathered[lane] : 0;
+        search_points(gi, lane < pending);
+        pending = 0;
+      }
+      if (need) gathered[pending + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint16_t)i;
+      pending += nneed;
     }
     QUEUE_MARK(0);
   };
 
-  // ---- one wave: row r of the slot's float64 partial sums — the matched pairs of slabs [r·kQMomentSlabs, …) --------------------
+  // ---- one wave: row r of the slot's float64 partial sums — the matched pairs of slabs [r·moment_slabs(), …) --------------------
   auto moment_task = [&](int q, int r) {
     QueueCtl* c = ctl_of(q);
     unsigned char* base = slot_of(q);
@@ -567,7 +696,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) a[k] = 0.0;
     double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
-    const int slab_lo = r * kQMomentSlabs, slab_hi = min(slab_lo + kQMomentSlabs, nslabs);
+    const int slab_lo = r * moment_slabs(nslabs), slab_hi = min(slab_lo + moment_slabs(nslabs), nslabs);
     for (int slab = slab_lo; slab < slab_hi; ++slab) {
       const int i = slab * kWave + lane;
       if (i < n) {
@@ -580,7 +709,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
           x = sp.x; y = sp.y;
           qx = rebuild64(qv.x, dv.x); qy = rebuild64(qv.y, dv.y);
         } else {
-          const float2 v = sh_src[i];
+          const float2 v = load_source(lay.src_off != 0xffffffffu, sh_src, sc.src_sorted + (int64_t)CTL_INT(cw, problem) * sc.src_stride, i);
           x = (double)v.x; y = (double)v.y;
           qx = (double)qv.x; qy = (double)qv.y;
         }
@@ -682,7 +811,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   // cycles per phase and search statistics summed over the waves of the launch (printed by the launcher under LSLAM_DEBUG)
   if (lay.debug && lane == 0) {
     for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(lay.queue + 4) + k, prof[k]);
-    for (int k = 0; k < 4; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(lay.queue + 4) + 6 + k, cnt[k]);
+    for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(lay.queue + 4) + 6 + k, cnt[k]);
   }
 #endif
 }
@@ -713,20 +842,41 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   const int nslabs = (int)((max_src_n + 63) / 64);
   auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
   QueueLayout lay{};
+  // Certificates pay once a run has iterations in which little moves (C4, 50 iterations: 4 % of the source visits still search, 16.6
+  // -> 6.9 ms); a LiDAR-sized pair stops after ~6 iterations, the sources it could skip in the last of them are scattered over all
+  // slabs, and the margins cost a slot of LDS (C3: 0.72 -> 0.85 ms): from 2048 points per cloud by default.
+  bool certify = max_src_n >= 2048 || max_tgt_n >= 2048;
+  if (const char* e = getenv("LSLAM_ICP_QUEUE_CERTIFY")) certify = atoi(e) != 0;
   const int rows_cap = kQRows;
-  size_t off = (size_t)nchunks * kQRec;
-  lay.slab_off = (uint32_t)off; off += (size_t)(nslabs > 0 ? nslabs : 1) * sizeof(float4);
-  lay.tdelta_off = (uint32_t)off; if (f64) off += (size_t)padded * sizeof(float2);
-  lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * (f64 ? sizeof(double2) : sizeof(float2)));
-  lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));
-  lay.rows_off = (uint32_t)off; off += sizeof(double) * ((size_t)rows_cap * RS + 16);
-  const size_t slot = up(off);
   lay.rows_cap = rows_cap;
+  // a slot's layout; float32 sources live in LDS when two slots still fit a CU, else they are read from the sorted copy in memory
+  // (once per search and once per moment task, coalesced: 4096-point problems then keep two slots per CU)
+  auto layout = [&](bool src_in_lds) -> size_t {
+    size_t off = (size_t)nchunks * kQRec;
+    lay.slab_off = (uint32_t)off; off += up((size_t)(nslabs > 0 ? nslabs : 1) * sizeof(float));
+    lay.tdelta_off = (uint32_t)off; if (f64) off += (size_t)padded * sizeof(float2);
+    lay.src_off = 0xffffffffu;
+    if (src_in_lds) { lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * (f64 ? sizeof(double2) : sizeof(float2))); }
+    lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));
+    lay.margin_off = (uint32_t)off; if (certify) off += up((size_t)max_src_n * sizeof(uint16_t));
+    lay.rows_off = (uint32_t)off; off += sizeof(double) * ((size_t)rows_cap * RS + 16);
+    return up(off);
+  };
+  auto slots_for = [&](size_t slot_bytes) -> int {
+    int q = 0;
+    while (q < 16 && (size_t)(q + 1) * kQCtlBytes + 192 + 2048 + (size_t)(q + 1) * slot_bytes <= kLdsPerCu) ++q;
+    return q;
+  };
+  size_t slot = layout(true);
+  int Q = slots_for(slot);
+  if (!f64 && Q < 2 && env_int("LSLAM_ICP_QUEUE_SRC_LDS", 0) == 0) {
+    const size_t lean = layout(false);
+    if (slots_for(lean) > Q) { slot = lean; Q = slots_for(lean); } else slot = layout(true);
+  }
+  if (Q < 1) return hipErrorInvalidValue;
   // geometry: one workgroup of W waves per CU holding Q slots
   int W = env_int("LSLAM_ICP_QUEUE_WAVES", 16);
   if (W < 1 || W > kIcpBatchMaxWaves) W = 16;
-  int Q = 1;
-  while (Q < 16 && (size_t)(Q + 1) * kQCtlBytes + 192 + (size_t)(Q + 1) * slot <= kLdsPerCu) ++Q;
   {
     // fewer problems than the chip has slots: spread them over the CUs
     const int64_t slots_needed = ((int64_t)S + cus - 1) / cus;
@@ -736,10 +886,13 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   }
   if (Q * (nslabs > 0 ? nslabs : 1) < W) W = Q * (nslabs > 0 ? nslabs : 1);      // no more waves than tasks can ever be open
   lay.slot_bytes = (uint32_t)slot;
-  lay.ctl_bytes = (uint32_t)up((size_t)Q * kQCtlBytes + 64 + 128);
+  lay.ctl_bytes = (uint32_t)up((size_t)Q * kQCtlBytes + 64 + 128 + (size_t)kIcpBatchMaxWaves * kWave * sizeof(uint16_t));
   lay.Q = Q;
   lay.G = env_int("LSLAM_ICP_QUEUE_G", 0);                     // slabs per search task; 0: one, two for problems above 32 slabs
-  if (nslabs > kQRows * kQMomentSlabs) return hipErrorInvalidValue;
+  if (nslabs > kQRows * 16) return hipErrorInvalidValue;
+  lay.certify = certify ? 1 : 0;
+  lay.ecap_frac = 0.25f;
+  if (const char* e = getenv("LSLAM_ICP_QUEUE_ECAP")) lay.ecap_frac = (float)atof(e);
   lay.queue = sc.queue;
   lay.debug = getenv("LSLAM_DEBUG") ? 1 : 0;
   const size_t smem = lay.ctl_bytes + (size_t)Q * slot;
@@ -748,17 +901,17 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   if (grid > cus) grid = cus;
   const int threads = W * 64;
   if (lay.debug) {
-    unsigned long long h[14];
+    unsigned long long h[16];
     (void)hipStreamSynchronize(stream);
-    (void)hipMemcpy(h, sc.queue, 112, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h, sc.queue, 128, hipMemcpyDeviceToHost);
     const unsigned* hu = reinterpret_cast<const unsigned*>(h);
     fprintf(stderr, "[lslam] queue kernel, previous launch: problems drawn %u, timeouts %u, tie passes %u\n", hu[0], hu[1], hu[2]);
 #ifdef LSLAM_QUEUE_PROFILE
     double tot = 0; for (int k = 0; k < 6; ++k) tot += (double)h[2 + k];
     if (tot > 0) fprintf(stderr, "[lslam] queue kernel, share of wave cycles: search %.3f  moments %.3f  reduce+solve %.3f  outputs+staging %.3f  idle %.3f  idle while draining %.3f\n",
                          h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot, h[7] / tot);
-    if (h[8] > 0) fprintf(stderr, "[lslam] queue kernel, per slab searched: %.2f surviving boxes, %.2f list rounds, %.2f (point, chunk) entries; %.0f cycles per slab\n",
-                          (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], tot / h[8]);
+    if (h[8] > 0) fprintf(stderr, "[lslam] queue kernel, per search of <= 64 sources: %.2f surviving boxes, %.2f list rounds, %.2f (point, chunk) entries; %.3f of the sources visited were searched (%.1f per search)\n",
+                          (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[13] / (double)(h[12] ? h[12] : 1), (double)h[13] / h[8]);
 #endif
     fprintf(stderr, "[lslam] icp_queue_kernel: %d workgroups x %d waves, %d slots of %zu B (%zu B LDS), %d rows per slot, %s\n",
             grid, W, Q, slot, smem, rows_cap, f64 ? "float64-exact" : "float32");
@@ -771,7 +924,8 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), smem, stream, a, sc, lay, S);
     return hipGetLastError();
   };
-  return f64 ? launch(icp_queue_kernel<true>) : launch(icp_queue_kernel<false>);
+  if (certify) return f64 ? launch(icp_queue_kernel<true, true>) : launch(icp_queue_kernel<false, true>);
+  return f64 ? launch(icp_queue_kernel<true, false>) : launch(icp_queue_kernel<false, false>);
 }
 
 }  // namespace lslam
