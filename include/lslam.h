@@ -211,6 +211,18 @@ int lslam_icp_large(const float *src, int64_t n, const float *tgt, int64_t m,
                     double *out_T, double *out_err, int32_t *out_iters,
                     int32_t *out_corr, int device);
 
+/* One pair, S start transforms: the reference's multi-start registration loop (code/icp_warm_up/test_icp.py:70-88: 24 yaw
+ * starts, one run_icp each) for clouds beyond the batched kernels.  Host clouds are validated and uploaded ONCE; the S runs
+ * (init_T: S x 16, outputs S x 16 / S / S, all host) follow each other on the device-resident pair. */
+int lslam_icp_large_starts(const float *src, int64_t n, const float *tgt, int64_t m, int dim,
+                           const double *init_T, int32_t S,
+                           double epsilon, double stopping_thresh, int32_t max_iters, uint32_t flags,
+                           double *out_T, double *out_err, int32_t *out_iters, int device);
+int lslam_icp_large_starts_f64(const double *src, int64_t n, const double *tgt, int64_t m, int dim,
+                               const double *init_T, int32_t S,
+                               double epsilon, double stopping_thresh, int32_t max_iters, uint32_t flags,
+                               double *out_T, double *out_err, int32_t *out_iters, int device);
+
 /* ---- single operators of modules/icp.py -------------------------------- */
 /* get_correspondences (icp.py:29-41) after the homogeneous transform of icp.py:116:
  * for every source point the index of the nearest target point (exact float32

@@ -42,6 +42,10 @@ SIGNATURES = {
     "lslam_valu_probe": (C.c_int, [C.c_int, C.c_void_p]),
     "lslam_host_staging": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
     "lslam_release_thread_resources": (C.c_int, []),
+    "lslam_icp_large_starts": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int32, C.c_double,
+                                         C.c_double, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "lslam_icp_large_starts_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int32, C.c_double,
+                                             C.c_double, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "lslam_icp_coop_fallbacks": (C.c_int, []),
     "lslam_icp_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_uint32, C.c_void_p,

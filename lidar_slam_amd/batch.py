@@ -106,7 +106,7 @@ def _pack_staged(clouds, dtype, slot):
             _STAGED_POINTS.clear()                                   # (the slot is shared by all shapes: forget what it held)
             _STAGED_POINTS[key] = total + total // 8 + 1024
             continue
-        if finite == 0:
+        if finite == 0:                                             # what _lib.check raises for LSLAM_ERR_NONFINITE (the reference: ValueError)
             raise ValueError("point clouds must be finite (NaN or Inf found)")
         flat = arr[: total * d].reshape(total, d).view(StagedClouds)
         flat.checked = True
@@ -126,6 +126,8 @@ def pack_clouds(clouds, dtype=None, staging=None):
         staged = _pack_staged(clouds, dtype, staging)
         if staged is not None:
             return staged
+    if dtype is None and not isinstance(clouds, PackedScans):
+        clouds = [c if isinstance(c, np.ndarray) else np.asarray(c) for c in clouds]
     if dtype is None:
         if isinstance(clouds, PackedScans) and clouds.packed() is not None:
             dtype = np.float32 if clouds.packed()[0].dtype == np.float32 else np.float64
@@ -135,7 +137,9 @@ def pack_clouds(clouds, dtype=None, staging=None):
         packed = clouds.packed()
         if packed is not None:
             return np.ascontiguousarray(packed[0], dtype=dtype), packed[1]
-    d = clouds[0].shape[1] if len(clouds) else 2
+    if not isinstance(clouds, PackedScans):                            # elements may be Python lists or other array-likes
+        clouds = [c if isinstance(c, np.ndarray) else np.asarray(c) for c in clouds]
+    d = clouds[0].shape[1] if len(clouds) and clouds[0].ndim == 2 else 2
     off = np.zeros(len(clouds) + 1, dtype=np.int64)
     off[1:] = np.cumsum([c.shape[0] for c in clouds])
     if any(c.ndim != 2 or c.shape[1] != d for c in clouds):

@@ -944,6 +944,65 @@ int lslam_icp_large_f64(const double* src, int64_t n, const double* tgt, int64_t
   return LSLAM_OK;
 }
 
+// One pair, S start transforms (the reference's 24-yaw multi-start loop, code/icp_warm_up/test_icp.py:70-88, on clouds too large for
+// the batched kernels): both clouds are uploaded ONCE and the S runs are enqueued back to back on the device-resident pair.
+extern "C++" {
+template <typename PT>
+static int icp_large_starts_host(const PT* src, int64_t n, const PT* tgt, int64_t m, int dim, const double* init_T, int32_t S,
+                                 double epsilon, double stopping_thresh, int32_t max_iters, uint32_t flags,
+                                 double* out_T, double* out_err, int32_t* out_iters, int device) {
+  constexpr bool kF64 = sizeof(PT) == sizeof(double);
+  clear_error();
+  if (dim != 2 && dim != 3) return fail(LSLAM_ERR_BAD_ARG, "dim must be 2 or 3, got %d", dim);
+  if (S < 0) return fail(LSLAM_ERR_BAD_ARG, "negative number of starts");
+  if (S == 0) return LSLAM_OK;
+  if (!src || !tgt || !init_T || !out_T || !out_err || !out_iters) return fail(LSLAM_ERR_BAD_ARG, "null pointer argument");
+  if (n <= 0) return fail(LSLAM_ERR_BAD_ARG, "empty source cloud");
+  if (m <= 0) return fail(LSLAM_ERR_EMPTY_TARGET, "empty target cloud");
+  bool finite;
+  if constexpr (kF64) finite = all_finite64(src, dim * n) && all_finite64(tgt, dim * m);
+  else finite = all_finite(src, dim * n) && all_finite(tgt, dim * m);
+  if (!finite) return fail(LSLAM_ERR_NONFINITE, "point clouds must be finite (NaN or Inf found)");
+  int rc;
+  if ((rc = use_device(device)) != LSLAM_OK) return rc;
+  Arena& ar = thread_arena();
+  const size_t cs = (size_t)dim * (size_t)n, ct = (size_t)dim * (size_t)m;
+  if ((rc = ar.reserve(device, Arena::align(4 * cs) + Arena::align(4 * ct) + (kF64 ? Arena::align(8 * cs) + Arena::align(8 * ct) : 0))) != LSLAM_OK) return rc;
+  float* d_src = static_cast<float*>(ar.carve(4 * cs));
+  float* d_tgt = static_cast<float*>(ar.carve(4 * ct));
+  double* d_src64 = kF64 ? static_cast<double*>(ar.carve(8 * cs)) : nullptr;
+  double* d_tgt64 = kF64 ? static_cast<double*>(ar.carve(8 * ct)) : nullptr;
+  hipStream_t st;
+  if ((rc = thread_stream(&st)) != LSLAM_OK) return rc;
+  if constexpr (kF64) {
+    LSLAM_HIP_TRY(hipMemcpyAsync(d_src64, src, 8 * cs, hipMemcpyHostToDevice, st));
+    LSLAM_HIP_TRY(hipMemcpyAsync(d_tgt64, tgt, 8 * ct, hipMemcpyHostToDevice, st));
+    LSLAM_HIP_TRY(launch_f64_to_f32(d_src64, d_src, (int64_t)cs, st));
+    LSLAM_HIP_TRY(launch_f64_to_f32(d_tgt64, d_tgt, (int64_t)ct, st));
+  } else {
+    LSLAM_HIP_TRY(hipMemcpyAsync(d_src, src, 4 * cs, hipMemcpyHostToDevice, st));
+    LSLAM_HIP_TRY(hipMemcpyAsync(d_tgt, tgt, 4 * ct, hipMemcpyHostToDevice, st));
+  }
+  for (int32_t k = 0; k < S; ++k) {
+    rc = lslam_icp_large_dev64(d_src, d_src64, n, d_tgt, d_tgt64, m, dim, init_T + 16 * (size_t)k, epsilon, stopping_thresh, max_iters, flags, 8,
+                               out_T + 16 * (size_t)k, out_err + k, out_iters + k, nullptr, st);
+    if (rc != LSLAM_OK) return rc;
+  }
+  return LSLAM_OK;
+}
+}  // extern "C++"
+
+int lslam_icp_large_starts(const float* src, int64_t n, const float* tgt, int64_t m, int dim, const double* init_T, int32_t S,
+                           double epsilon, double stopping_thresh, int32_t max_iters, uint32_t flags,
+                           double* out_T, double* out_err, int32_t* out_iters, int device) {
+  return icp_large_starts_host<float>(src, n, tgt, m, dim, init_T, S, epsilon, stopping_thresh, max_iters, flags, out_T, out_err, out_iters, device);
+}
+int lslam_icp_large_starts_f64(const double* src, int64_t n, const double* tgt, int64_t m, int dim, const double* init_T, int32_t S,
+                               double epsilon, double stopping_thresh, int32_t max_iters, uint32_t flags,
+                               double* out_T, double* out_err, int32_t* out_iters, int device) {
+  return icp_large_starts_host<double>(src, n, tgt, m, dim, init_T, S, epsilon, stopping_thresh, max_iters, flags, out_T, out_err, out_iters, device);
+}
+
 int lslam_nn(const float* src, int64_t n, const float* tgt, int64_t m, int dim, const double* T,
              int32_t* out_idx, float* out_d2, int device) {
   clear_error();

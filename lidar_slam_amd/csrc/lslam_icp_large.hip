@@ -546,6 +546,8 @@ moments64_kernel(MomArgs a) {
     __syncthreads();
     const int64_t i = base + tid;
     double pd[DIM];
+    int my_entry = -1;                                         // this thread's near-tie entry: its OWNER adds the pair to its sums (which slot the
+                                                               // atomic handed out must not decide who sums what: the sums are bitwise reproducible)
     if (i < a.n) {
       unsigned long long kmin = kKeyInit;
       float v1 = INFINITY, v2 = INFINITY;
@@ -569,6 +571,7 @@ moments64_kernel(MomArgs a) {
       const float lim = near_lim(v1, nt);
       if (v2 <= lim) {                                         // near tie: the workgroup decides it below
         const int e = atomicAdd(&s_count, 1);
+        my_entry = e;
         s_ent[e][0] = (double)lim;
 #pragma unroll
         for (int r = 0; r < DIM; ++r) {
@@ -613,14 +616,13 @@ moments64_kernel(MomArgs a) {
         }
         __syncthreads();
       }
-      if (tid < ne) {                                          // thread e finishes entry e
-        const int64_t i = (int64_t)s_ent[tid][7];
-        const int bj = s_bj[tid];
+      if (my_entry >= 0) {                                     // the source's own thread finishes its entry
+        const int bj = s_bj[my_entry];
         if (a.out_corr) a.out_corr[i] = bj;
-        double p[DIM], q[DIM];
+        double q[DIM];
 #pragma unroll
-        for (int r = 0; r < DIM; ++r) { p[r] = s_ent[tid][4 + r]; q[r] = a.tgt64[DIM * (int64_t)bj + r]; }
-        acc.add(p, q, box);
+        for (int r = 0; r < DIM; ++r) q[r] = a.tgt64[DIM * (int64_t)bj + r];
+        acc.add(pd, q, box);
       }
       __syncthreads();
     }

@@ -57,7 +57,7 @@ namespace lslam {
 constexpr int kQCtlBytes = 256;
 constexpr long long kQTimeoutTicks = 400000000ll;      // 4 s of the 100 MHz wall clock
 constexpr int kQRec = kPruneChunk * 8 + 16;            // bytes per chunk record: 16 targets + the chunk's box
-constexpr int kQRows = 8;                              // rows of float64 partial sums per slot (moment_slabs: one row up to 20 slabs, 8 slabs per row up to 64, 16 up to 128)
+constexpr int kQRows = 16;                             // rows of float64 partial sums per slot (moment_slabs: one row up to 20 slabs, 8 slabs per row up to 64, 16 up to 128)
 constexpr float kQExtend = 4.f;                        // E = kQExtend × the last step's largest displacement (capped): what a search pays for later certificates
 constexpr float kQPad = 1.0e18f;                       // x of the padding targets (times 1 + slot/16), y = 0
 constexpr float kQFarD2 = 1.0e35f;                     // a best distance beyond this is not trusted (padding, overflow): exhaustive pass
@@ -219,12 +219,17 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   auto search_group = [&](int nslabs, int it) -> int {
     if (lay.G > 0) return lay.G;
     if (it == 0 || !CERT) return nslabs > 32 ? 2 : 1;
-    return nslabs > 32 ? 8 : 4;
+    const int fill = nslabs * Q / nwaves;                      // every wave a task when the slots open together
+    const int most = nslabs > 32 ? 8 : 4;
+    return fill < 2 ? 2 : (fill > most ? most : fill);
   };
 #ifndef QEXP_MOM
 #define QEXP_MOM 20
 #endif
-  auto moment_slabs = [&](int nslabs) -> int { return nslabs <= QEXP_MOM ? (nslabs > 0 ? nslabs : 1) : (nslabs <= 64 ? 8 : 16); };
+#ifndef QEXP_MOMBIG
+#define QEXP_MOMBIG 8
+#endif
+  auto moment_slabs = [&](int nslabs) -> int { return nslabs <= QEXP_MOM ? (nslabs > 0 ? nslabs : 1) : (nslabs <= 64 ? QEXP_MOMBIG : 2 * QEXP_MOMBIG); };
   auto moment_tasks = [&](int nslabs) -> int { return nslabs > 0 ? (nslabs + moment_slabs(nslabs) - 1) / moment_slabs(nslabs) : 1; };
 
   // ---- one wave: draw the next problem and stage it into slot q (or mark the slot empty for good) ----
@@ -889,7 +894,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   lay.ctl_bytes = (uint32_t)up((size_t)Q * kQCtlBytes + 64 + 128 + (size_t)kIcpBatchMaxWaves * kWave * sizeof(uint16_t));
   lay.Q = Q;
   lay.G = env_int("LSLAM_ICP_QUEUE_G", 0);                     // slabs per search task; 0: one, two for problems above 32 slabs
-  if (nslabs > kQRows * 16) return hipErrorInvalidValue;
+  if (nslabs > kQRows * 2 * QEXP_MOMBIG) return hipErrorInvalidValue;
   lay.certify = certify ? 1 : 0;
   lay.ecap_frac = 0.25f;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_ECAP")) lay.ecap_frac = (float)atof(e);

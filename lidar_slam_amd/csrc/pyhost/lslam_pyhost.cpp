@@ -26,13 +26,14 @@ namespace {
 
 struct Item { const void* ptr; int64_t n; int is_f64; };
 
+// copies and converts; finiteness is that of the CONVERTED value (a finite double beyond the float32 range becomes ±inf)
 template <typename S, typename D>
 bool copy_check(const S* s, D* d, int64_t count) {
   bool finite = true;
   for (int64_t i = 0; i < count; ++i) {
-    const S v = s[i];
+    const D v = (D)s[i];
     finite &= std::isfinite(v);
-    d[i] = (D)v;
+    d[i] = v;
   }
   return finite;
 }
@@ -46,19 +47,24 @@ PyObject* pack_list(PyObject*, PyObject* args) {
   if (!PyList_Check(list) || dim < 1 || dim > 3) Py_RETURN_NONE;
   const Py_ssize_t K = PyList_GET_SIZE(list);
   std::vector<Item> items((size_t)K);
+  // The buffer views are HELD until the copying threads have joined: the GIL is dropped while they read the arrays' memory, and
+  // an exported buffer pins it (another Python thread that resizes an array or edits the list cannot free what is being read).
+  std::vector<Py_buffer> views;
+  views.reserve((size_t)K);
+  auto release_views = [&]() { for (auto& v : views) PyBuffer_Release(&v); views.clear(); };
   int64_t* off = reinterpret_cast<int64_t*>(off_addr);
   int64_t total = 0, n_f64 = 0;
   off[0] = 0;
   for (Py_ssize_t k = 0; k < K; ++k) {
     Py_buffer b;
-    if (PyObject_GetBuffer(PyList_GET_ITEM(list, k), &b, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) { PyErr_Clear(); Py_RETURN_NONE; }
+    if (PyObject_GetBuffer(PyList_GET_ITEM(list, k), &b, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) { PyErr_Clear(); release_views(); Py_RETURN_NONE; }
+    views.push_back(b);
     const bool f64 = b.format && b.format[0] == 'd' && b.format[1] == 0, f32 = b.format && b.format[0] == 'f' && b.format[1] == 0;
     const bool ok = (f64 || f32) && b.ndim == 2 && b.shape[1] == dim;
-    if (ok) { items[(size_t)k] = Item{b.buf, (int64_t)b.shape[0], f64 ? 1 : 0}; total += b.shape[0]; off[k + 1] = total; n_f64 += f64 ? 1 : 0; }
-    PyBuffer_Release(&b);            // the list keeps the arrays alive for the duration of this call
-    if (!ok) Py_RETURN_NONE;
+    if (!ok) { release_views(); Py_RETURN_NONE; }
+    items[(size_t)k] = Item{b.buf, (int64_t)b.shape[0], f64 ? 1 : 0}; total += b.shape[0]; off[k + 1] = total; n_f64 += f64 ? 1 : 0;
   }
-  if (total > cap) return Py_BuildValue("(LiL)", (long long)total, -1, (long long)n_f64);      // destination too small: nothing copied, the caller grows it
+  if (total > cap) { release_views(); return Py_BuildValue("(LiL)", (long long)total, -1, (long long)n_f64); }      // destination too small: nothing copied, the caller grows it
   std::atomic<int> finite{1};
   if (threads < 1) threads = 1;
   if (threads > 64) threads = 64;
@@ -90,6 +96,7 @@ PyObject* pack_list(PyObject*, PyObject* args) {
     for (auto& th : pool) th.join();
   }
   Py_END_ALLOW_THREADS
+  release_views();
   return Py_BuildValue("(LiL)", (long long)total, finite.load(), (long long)n_f64);
 }
 

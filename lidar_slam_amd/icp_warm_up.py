@@ -64,12 +64,11 @@ def register_multi_start(source_pc, target_pc, n_starts=24, epsilon=0.001, voxel
     s32 = np.ascontiguousarray(icp._xyz(src)[:, :d], dtype=dtype)
     t32 = np.ascontiguousarray(icp._xyz(tgt)[:, :d], dtype=dtype)
     if n * m > SEQUENTIAL_PAIR_EVALS:
+        # whole-chip runs, back to back on ONE upload of the pair (lslam_icp_large_starts)
         poses, errors, iters = np.empty((S, 4, 4)), np.empty(S), np.zeros(S, dtype=np.int32)
-        entry = lib().lslam_icp_large_f64 if dtype == np.float64 else lib().lslam_icp_large
-        for k in range(S):
-            check(entry(ptr(s32), n, ptr(t32), m, d, ptr(np.ascontiguousarray(init[k])), float(epsilon),
-                        float(stopping_thresh), int(max_iters), ICP_NORMALIZE_ERROR, ptr(poses[k]),
-                        ptr(errors[k:k + 1]), ptr(iters[k:k + 1]), None, icp._DEVICE))
+        entry = lib().lslam_icp_large_starts_f64 if dtype == np.float64 else lib().lslam_icp_large_starts
+        check(entry(ptr(s32), n, ptr(t32), m, d, ptr(np.ascontiguousarray(init, dtype=np.float64)), S, float(epsilon),
+                    float(stopping_thresh), int(max_iters), ICP_NORMALIZE_ERROR, ptr(poses), ptr(errors), ptr(iters), icp._DEVICE))
     else:
         r = icp_batch(_tiled([s32], S, S * n, d, 0), np.arange(S + 1, dtype=np.int64) * n, _tiled([t32], S, S * m, d, 1),
                       np.arange(S + 1, dtype=np.int64) * m, init, epsilon=epsilon, max_iters=max_iters,

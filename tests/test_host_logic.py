@@ -2,6 +2,7 @@
 list the reference's pre-processing returns, localization.py:252-307 / main.py:84-87)."""
 
 import numpy as np
+import pytest
 
 from lidar_slam_amd.batch import PackedScans, pack_clouds
 
@@ -116,3 +117,20 @@ def test_tiled_copies_for_multi_start_registration(monkeypatch):
     assert out.dtype == a.dtype and out.flags["C_CONTIGUOUS"]
     out32 = w._tiled([a.astype(np.float32)], 2, 8, 3, 1)
     assert out32.dtype == np.float32 and out32.shape == (8, 3)
+
+
+def test_pack_clouds_accepts_what_the_c_helper_declines():
+    """elements that are Python lists, non-contiguous views or integer arrays: the NumPy path normalises them (with or without
+    the C helper / a device), same packed result"""
+    from lidar_slam_amd.batch import pack_clouds
+    base = np.arange(24.0).reshape(12, 2)
+    clouds = [[[0.0, 1.0], [2.0, 3.0]], base[::3], np.zeros((0, 2)), np.array([[5, 6]])]
+    want = np.concatenate([np.asarray(c, dtype=np.float64).reshape(-1, 2) for c in clouds])
+    for staging in (None, 0):
+        flat, off = pack_clouds(clouds, staging=staging)
+        assert flat.dtype == np.float64 and np.array_equal(flat, want)
+        assert off.tolist() == [0, 2, 6, 6, 7]
+    flat32, _ = pack_clouds([np.ones((3, 2), np.float32), [[1.0, 2.0]]], dtype=np.float32)
+    assert flat32.dtype == np.float32 and flat32.shape == (4, 2)
+    with pytest.raises(ValueError):
+        pack_clouds([np.ones((3, 2)), np.ones((3, 3))])
