@@ -216,6 +216,18 @@ __device__ __forceinline__ float near_lim(float D, const NearTie& nt) {
   return x * x * 1.000002f + 1e-37f;
 }
 
+// float64-exact mode, float64 points kept on chip at 4 bytes per coordinate beside their float32 rounding: the residual
+// t64 − f64(t32) is a multiple of 2^(e − 54), e = frexp exponent of t32, and smaller than 2²⁹ of them — an int32 count from which
+// f64(t32) + ldexp(count, e − 54) restores the float64 coordinate bit for bit (t32 = 0 or subnormal: to within 2⁻¹⁵⁰).
+__device__ __forceinline__ int residual_count(double t64, float t32) {
+  const int e = __builtin_amdgcn_frexp_expf(t32);
+  return (int)rint(ldexp(t64 - (double)t32, 54 - e));
+}
+__device__ __forceinline__ double rebuild64(float t32, int count) {
+  const int e = __builtin_amdgcn_frexp_expf(t32);
+  return (double)t32 + ldexp((double)count, e - 54);
+}
+
 // After the sweep: does the second chunk have to be re-evaluated (`two`), and is a third chunk (or an overflow risk)
 // in play so that the exact sweep must run instead (`third`)?  Rt ≥ the largest |t| swept.  Every comparison is
 // written so that a NaN sends the caller to the exact sweep.  In float64-exact mode the chunks kept must hold every

@@ -251,7 +251,11 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
   TP* tile = reinterpret_cast<TP*>(smem);
   float* wtile = reinterpret_cast<float*>(smem + args.tile_bytes);            // |t|² per target (planar FILTER build; 3-D keeps it in .w)
   float* sh_src = reinterpret_cast<float*>(smem + args.tile_bytes + args.w_bytes);   // the source cloud, DIM floats per point
-  double* sh_red = reinterpret_cast<double*>(smem + args.tile_bytes + args.w_bytes + args.src_bytes);   // [waves][kAcc]
+  // float64-exact mode: the float64 clouds on chip as residual counts beside their float32 copies (lslam_device.h: rebuild64) — the
+  // moments of every iteration then come from LDS instead of re-reading 16 bytes per source and per matched target from memory
+  int* res_tgt = reinterpret_cast<int*>(smem + args.tile_bytes + args.w_bytes + args.src_bytes);        // DIM per target of the tile
+  int* res_src = res_tgt + (size_t)args.tile_points * DIM;                                                 // DIM per source
+  double* sh_red = reinterpret_cast<double*>(smem + args.tile_bytes + args.w_bytes + args.src_bytes + args.res_bytes);   // [waves][kAcc]
   double* sh_T = sh_red + (size_t)kIcpBatchMaxWaves * kAcc;                   // current transform, 16
   // loop state of run_icp (icp.py:163-181) and the last error: wave 0 is the only reader and writer, and the values are
   // wave-uniform — in LDS they cost nothing, in registers they were spilled around the solve (stores in every iteration)
@@ -303,6 +307,18 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
     }
   };
   __syncthreads();
+  const bool res_resident = F64 && args.res_bytes != 0 && resident && src_resident;
+  if constexpr (F64) {
+    if (res_resident) {
+      for (int j = tid; j < m; j += blockDim.x) {
+        const TP v = tile[j];
+        res_tgt[DIM * j] = residual_count(gtgt64[(int64_t)DIM * j], v.x);
+        res_tgt[DIM * j + 1] = residual_count(gtgt64[(int64_t)DIM * j + 1], v.y);
+        if constexpr (DIM == 3) res_tgt[DIM * j + 2] = residual_count(gtgt64[(int64_t)DIM * j + 2], v.z);
+      }
+      for (int i = tid; i < n * DIM; i += blockDim.x) res_src[i] = residual_count(gsrc64[i], sh_src[i]);
+    }
+  }
   float Rt = 0.f;                                              // ≥ the largest |t| of the problem
   if constexpr (FILTER) {
     // |t|² beside every target (+inf on the padding: g = +inf there, the padding coordinates never produce a NaN
@@ -462,12 +478,12 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
           two[p] &= owns; third[p] &= owns;
           nthird += __popcll(__ballot(third[p]));
         }
-        f_tries++;
+        f_tries = __builtin_amdgcn_readfirstlane(f_tries + 1);   // wave-uniform: stays in a scalar register (as a vector value it was spilled, one scratch store per iteration and lane)
         if (args.debug && lane == 0) atomicAdd(args.debug, 1u);
         // a few such points are searched one by one by the whole wave (coop_exact: ≈ m/8 instructions each, against ≈ 5·m·P for
         // the exact sweep); on lattices and on clouds far from the origin most points are: exact sweep
         if (nthird > 8 * P) {
-          f_fails++;
+          f_fails = __builtin_amdgcn_readfirstlane(f_fails + 1);
           if (args.debug && lane == 0) atomicAdd(args.debug + 1, 1u);
         } else {
 #pragma unroll
@@ -584,7 +600,13 @@ __device__ __forceinline__ void icp_batch_body(const IcpBatchArgs& args) {
       if (i < n) {
         double x, y, z = 0.0;
         double pd[DIM], qd[DIM];
-        if (f64) {                                             // the float64 points themselves: icp.py:116-118 as the reference computes them
+        if (f64 && res_resident) {                             // the float64 points themselves, restored from their on-chip residuals
+          x = rebuild64(sh_src[DIM * i], res_src[DIM * i]); y = rebuild64(sh_src[DIM * i + 1], res_src[DIM * i + 1]);
+          if constexpr (DIM == 3) z = rebuild64(sh_src[DIM * i + 2], res_src[DIM * i + 2]);
+          const TP v = tile[bi[p]];
+          qd[0] = rebuild64(v.x, res_tgt[DIM * bi[p]]); qd[1] = rebuild64(v.y, res_tgt[DIM * bi[p] + 1]);
+          if constexpr (DIM == 3) qd[2] = rebuild64(v.z, res_tgt[DIM * bi[p] + 2]);
+        } else if (f64) {                                      // the float64 points themselves: icp.py:116-118 as the reference computes them
           x = gsrc64[(int64_t)DIM * i]; y = gsrc64[(int64_t)DIM * i + 1];
           if constexpr (DIM == 3) z = gsrc64[(int64_t)DIM * i + 2];
 #pragma unroll
@@ -741,6 +763,8 @@ static hipError_t launch_one_mode(const IcpBatchArgs& a, int S, int threads, siz
 // the float64-exact builds exist for 1, 2 and 4 points per lane (the launcher never picks 8 in that mode)
 template <int DIM, int P>
 static hipError_t launch_one(const IcpBatchArgs& a, int S, int threads, size_t smem, Build build, hipStream_t stream) {
+  // (P = 8 in this mode was built and measured in round 4: 824 bytes of scratch per lane, and its two 8-wave workgroups per CU
+  // have no LDS left for the float64 residuals — 319 ms on C4 against 190 ms for the P = 4 build)
   if constexpr (P <= 4)
     if (a.src64) return launch_one_mode<DIM, P, true>(a, S, threads, smem, build, stream);
   return launch_one_mode<DIM, P, false>(a, S, threads, smem, build, stream);
@@ -798,7 +822,17 @@ hipError_t launch_icp_batch(IcpBatchArgs a, int dim, int S, int64_t max_src_n, i
   const size_t budget = small ? 36 * 1024 : (threads <= 512 ? 78 * 1024 : 128 * 1024);
   const size_t src_need = (((size_t)max_src_n * dim * sizeof(float)) + 15) & ~(size_t)15;
   a.src_bytes = (a.tile_bytes + a.w_bytes + src_need <= budget && tune.src_in_lds != 2) || tune.src_in_lds == 1 ? (uint32_t)src_need : 0u;
-  const size_t smem = a.tile_bytes + a.w_bytes + a.src_bytes + sizeof(double) * ((size_t)kIcpBatchMaxWaves * kAcc + 16 + 1) + sizeof(StopState) + 16;
+  // float64-exact mode: the residual counts of both clouds on chip as well while everything fits one CU's LDS (the big builds run one
+  // workgroup per CU anyway; C4: 32 + 16 + 32 + 64 KB): HBM then sees each cloud once per problem in this mode too
+  a.res_bytes = 0;
+  {
+    const size_t fixed = sizeof(double) * ((size_t)kIcpBatchMaxWaves * kAcc + 16 + 1) + sizeof(StopState) + 16;
+    const size_t res_need = (((size_t)tile_points + (size_t)max_src_n) * dim * sizeof(int) + 15) & ~(size_t)15;
+    if (a.src64 && !small && a.src_bytes != 0 && max_tgt_n <= tile_points &&
+        a.tile_bytes + a.w_bytes + a.src_bytes + res_need + fixed <= 160 * 1024 && !getenv("LSLAM_ICP_NO_RESIDUALS"))
+      a.res_bytes = (uint32_t)res_need;
+  }
+  const size_t smem = a.tile_bytes + a.w_bytes + a.src_bytes + a.res_bytes + sizeof(double) * ((size_t)kIcpBatchMaxWaves * kAcc + 16 + 1) + sizeof(StopState) + 16;
   const Build build = small ? Build::kSmall : (filter ? Build::kFilter : Build::kBig);
   static unsigned* dbg = nullptr;
   if (getenv("LSLAM_DEBUG")) {

@@ -90,16 +90,6 @@ __device__ __forceinline__ int lds_load_i32(const int32_t* p) {
   return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
 
-// float64-exact mode: a float64 coordinate from its float32 rounding and the residual count (see the header of this file)
-__device__ __forceinline__ int residual_count(double t64, float t32) {
-  const int e = __builtin_amdgcn_frexp_expf(t32);
-  return (int)rint(ldexp(t64 - (double)t32, 54 - e));
-}
-__device__ __forceinline__ double rebuild64(float t32, int count) {
-  const int e = __builtin_amdgcn_frexp_expf(t32);
-  return (double)t32 + ldexp((double)count, e - 54);
-}
-
 // a slot's control block through ONE load: lane k holds dword k, fields come out with v_readlane (wave-uniform, in scalar registers)
 __device__ __forceinline__ int ctl_load(const QueueCtl* c, int lane) {
   return __hip_atomic_load(reinterpret_cast<const int*>(c) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

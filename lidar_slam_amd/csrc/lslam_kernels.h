@@ -43,6 +43,7 @@ struct IcpBatchArgs {
   uint32_t tile_bytes;       // filled by the launcher
   uint32_t src_bytes;        // filled by the launcher: LDS reserved for the source cloud (0 = read it from memory)
   uint32_t w_bytes;          // filled by the launcher: LDS reserved for |t|² per target (planar filter build, else 0)
+  uint32_t res_bytes;        // filled by the launcher: float64-exact mode, LDS for the int32 residual counts of target and source (0 = read the float64 clouds from memory)
   unsigned* debug;           // LSLAM_DEBUG: [0] filter passes attempted, [1] passes that fell back to the exact sweep (or nullptr)
   // float64-exact mode (both set, or both nullptr): the same clouds in float64, laid out like src / tgt.  The float32
   // search then only proposes candidates; near ties are decided, and the moments accumulated, on these points — the
