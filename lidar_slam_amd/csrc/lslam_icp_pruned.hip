@@ -800,13 +800,12 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   hipLaunchKernelGGL(icp_sort_kernel, dim3(S), dim3(kSortThreads), sort_lds, stream, a, sc, len, keep, curve, cap, cur_words);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  // 2. iterate.  The task-queue kernel (lslam_icp_queue.hip: problems in LDS slots, waves draw tasks, no barriers): LiDAR-sized
-  // float32 clouds (C3 sequence: 0.72 ms against 0.87), and clouds from 2048 points, where it also keeps a source's match from one
-  // iteration to the next while a proof allows it (C4, 50 iterations: 6.9 ms against 16.0; float64-exact 12.8 against 17.9).  One
-  // problem per workgroup (below) for LiDAR-sized float64-exact clouds — they take twice the LDS, four slots per CU leave the
-  // queue little to fill a finishing problem's gap with (C3: 0.99 against 0.96 ms).  LSLAM_ICP_PRUNE_QUEUE=1 / 0 forces either.
+  // 2. iterate: the task-queue kernel (lslam_icp_queue.hip: problems in LDS slots, waves draw tasks, no barriers; from 2048 points
+  // per cloud it also keeps a source's match from one iteration to the next while a proof allows it).  Round 4, same boxes: C3
+  // sequence 0.77 ms against 0.87 (float64-exact 0.91 against 0.96), C4 with 50 iterations 6.7 ms against 16.0 (float64-exact 12.5
+  // against 17.9).  LSLAM_ICP_PRUNE_QUEUE=0 keeps one problem per workgroup (the kernel below).
   {
-    bool queue = a.src64 == nullptr || max_src_n >= 2048 || max_tgt_n >= 2048;
+    bool queue = true;
     if (const char* env = getenv("LSLAM_ICP_PRUNE_QUEUE")) queue = atoi(env) != 0;
     if (queue && sc.queue) return launch_icp_queue(a, sc, S, max_src_n, max_tgt_n, stream);
   }

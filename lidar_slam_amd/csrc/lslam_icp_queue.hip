@@ -112,6 +112,17 @@ __device__ __forceinline__ float2 load_source(bool in_lds, const float2* lds, co
   return v;
 }
 
+__device__ __forceinline__ double2 load_source64(bool in_lds, const double2* lds, const double2* mem, int i) {
+  double2 v;
+  if (in_lds) {
+    v = lds[i];
+  } else {
+    v = mem[i];
+    asm volatile("" : "+v"(v.x), "+v"(v.y));
+  }
+  return v;
+}
+
 // byte offset of sorted target j inside a slot's records
 __device__ __forceinline__ unsigned rec_off(int j) { return (unsigned)(j >> 4) * kQRec + (unsigned)(j & 15) * 8u; }
 
@@ -269,7 +280,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int i = i0 + u * kWave + lane; pd[u] = i < n ? sc.src64_sorted[ss + i] : make_double2(0.0, 0.0); }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u * kWave + lane; if (i < n) sh_src64[i] = pd[u]; }
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * kWave + lane; if (i < n && src_lds) sh_src64[i] = pd[u]; }
       } else if (src_lds) {
         float2 v[8];
 #pragma unroll
@@ -289,7 +300,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       float p2 = 0.f;
       if (i < n) {
         float vx, vy;
-        if constexpr (F64) { const double2 pd = sh_src64[i]; vx = (float)pd.x; vy = (float)pd.y; }
+        if constexpr (F64) { const double2 pd = load_source64(src_lds, sh_src64, sc.src64_sorted + ss, i); vx = (float)pd.x; vy = (float)pd.y; }
         else { const float2 v = load_source(src_lds, sh_src, sc.src_sorted + ss, i); vx = v.x; vy = v.y; }
         p2 = __builtin_fmaf(vy, vy, vx * vx);
       }
@@ -432,6 +443,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     const int p = CTL_INT(cw, problem);
     const float stepR = CERT ? CTL_FLOAT(cw, stepR) : INFINITY, stepT = CERT ? CTL_FLOAT(cw, stepT) : INFINITY, extend = CERT ? CTL_FLOAT(cw, extend) : 0.f;
     const float2* __restrict__ gsrc = sc.src_sorted + (int64_t)p * sc.src_stride;
+    const double2* __restrict__ gsrc64 = F64 ? sc.src64_sorted + (int64_t)p * sc.src_stride : nullptr;
     double T[2][4];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -461,7 +473,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       float ax = 0.f, ay = 0.f;
       if (owns) {
         float2 v;
-        if constexpr (F64) { const double2 pd = sh_src64[i]; v = make_float2((float)pd.x, (float)pd.y); }
+        if constexpr (F64) { const double2 pd = load_source64(src_lds, sh_src64, gsrc64, i); v = make_float2((float)pd.x, (float)pd.y); }
         else v = load_source(src_lds, sh_src, gsrc, i);
         ax = (float)(T[0][0] * (double)v.x + T[0][1] * (double)v.y + T[0][3]);      // icp.py:116
         ay = (float)(T[1][0] * (double)v.x + T[1][1] * (double)v.y + T[1][3]);
@@ -558,7 +570,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
           const float lim = far ? INFINITY : (near ? near_lim(bd, nt) : -INFINITY);
           double adx = 0.0, ady = 0.0;
           if (near || far) {
-            const double2 pd = sh_src64[i];
+            const double2 pd = load_source64(src_lds, sh_src64, gsrc64, i);
             adx = T[0][0] * pd.x + T[0][1] * pd.y + T[0][3];
             ady = T[1][0] * pd.x + T[1][1] * pd.y + T[1][3];
           }
@@ -699,7 +711,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         double x, y, qx, qy;
         const float2 qv = *reinterpret_cast<const float2*>(base + rec_off(ps));
         if constexpr (F64) {
-          const double2 sp = sh_src64[i];
+          const double2 sp = load_source64(lay.src_off != 0xffffffffu, sh_src64, sc.src64_sorted + (int64_t)CTL_INT(cw, problem) * sc.src_stride, i);
           const int2 dv = tdelta[ps];
           x = sp.x; y = sp.y;
           qx = rebuild64(qv.x, dv.x); qy = rebuild64(qv.y, dv.y);
@@ -864,7 +876,8 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   };
   size_t slot = layout(true);
   int Q = slots_for(slot);
-  if (!f64 && Q < 2 && env_int("LSLAM_ICP_QUEUE_SRC_LDS", 0) == 0) {
+  const int lean_below = env_int("LSLAM_ICP_QUEUE_LEAN_BELOW", f64 ? 0 : 2);      // sources out of LDS when fewer slots than this fit with them
+  if (Q < lean_below && env_int("LSLAM_ICP_QUEUE_SRC_LDS", 0) == 0) {
     const size_t lean = layout(false);
     if (slots_for(lean) > Q) { slot = lean; Q = slots_for(lean); } else slot = layout(true);
   }
