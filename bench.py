@@ -65,7 +65,23 @@ def profile_figures(workload, kernel, root=None, current_hash=None):
         return {"stale_profile": f"{os.path.relpath(f, root)} profiles {e.get('kernel')}, this run launches {kernel}"}
     return {"hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "lane_ops_per_pair_eval": e.get("lane_ops_per_pair_eval"),
             "issue_utilisation": e.get("valu_instruction_issue_utilisation_at_2_cycles_per_wave64"),
-            "source": os.path.relpath(f, root)}
+            "wait_fraction": e.get("wait_fraction_of_wave_cycles"), "valu_lane_ops_per_launch": e.get("valu_lane_ops_per_launch"),
+            "compulsory_bytes_per_launch": e.get("compulsory_bytes_per_launch"), "ratio_to_compulsory": e.get("ratio_to_compulsory"),
+            "kernel_ms_under_pmc": e.get("kernel_ms_under_pmc"), "source": os.path.relpath(f, root)}
+
+
+def kernel_roofline(tag, kernel, kernel_ms, pair_evals, flop_per_pair, note):
+    """roofline object of a kernel other than the headline's: HIP-event duration of this run, the N x M pair evaluations the
+    launch is EQUIVALENT to priced at the algorithmic flop count (for an exact pruning kernel that is work it avoided: `frac` may
+    exceed 1 and says how far the search is from brute force, not how busy the ALUs are — `issue_utilisation` does), and the PMC
+    figures of the committed profile (tools/profile_round.sh) while it matches these sources and this kernel."""
+    prof = profile_figures(tag, kernel)
+    achieved = pair_evals * flop_per_pair / (kernel_ms * 1e-3) / 1e12
+    return {"kernel": kernel, "bound": "valu", "kernel_ms": kernel_ms, "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "pair_evals_equivalent_per_s": pair_evals / (kernel_ms * 1e-3),
+            "traffic": prof.get("hbm_bytes_per_launch"), "compulsory_bytes": prof.get("compulsory_bytes_per_launch"),
+            "traffic_ratio_to_compulsory": prof.get("ratio_to_compulsory"), "issue_utilisation": prof.get("issue_utilisation"),
+            "wait_fraction": prof.get("wait_fraction"), "stale_profile": prof.get("stale_profile"), "profile": prof.get("source"), "note": note}
 
 
 def parse():
@@ -139,14 +155,23 @@ def _pool_job(args):
     return icp_oracle.run_icp_full(src, tgt, init, epsilon=0.0, stopping_thresh=0.0, max_iters=iters - 1).iterations
 
 
+def _pool_ready(_):
+    from oracle import icp_oracle                                    # import in the worker before the clock starts
+    return os.getpid()
+
+
 def cpu_baseline_all_cores(src, tgt, init, P, n_pairs, iters):
+    """the same port on every host core: a fork pool that is started and warmed BEFORE the clock (round 3 timed the start of a
+    256-process pool around one 60 ms job per worker), at least 8 pairs per worker; returns (iterations/s, workers, pairs)"""
     import multiprocessing as mp
     cores = os.cpu_count() or 1
     jobs = [(src[k * P:(k + 1) * P], tgt[k * P:(k + 1) * P], init[k], iters) for k in range(n_pairs)]
-    t0 = time.perf_counter()
     with mp.get_context("fork").Pool(cores) as pool:
+        workers = len(set(pool.map(_pool_ready, range(4 * cores), chunksize=1)))
+        t0 = time.perf_counter()
         total = sum(pool.map(_pool_job, jobs, chunksize=1))
-    return total / (time.perf_counter() - t0), cores
+        dt = time.perf_counter() - t0
+    return total / dt, cores, workers, n_pairs
 
 
 # -------------------------------------------------------------------------------------- launcher
@@ -254,11 +279,14 @@ def main():
         w = synth.batch_c4(n, a.points, seed=1000)              # same distribution as the device-side generator below
         h_src, h_tgt = w.src.astype(np.float64), w.tgt.astype(np.float64)
         v, secs, its = cpu_baseline_icp(h_src, h_tgt, w.init_T, a.points, n, a.iters)
-        vall, cores = cpu_baseline_all_cores(h_src, h_tgt, w.init_T, a.points, n, a.iters)
+        n_all = min(max(n, 8 * (os.cpu_count() or 1)), 4096)                # at least 8 pairs per worker
+        wa = w if n_all == n else synth.batch_c4(n_all, a.points, seed=1000)
+        vall, cores, workers, n_all = cpu_baseline_all_cores(wa.src.astype(np.float64), wa.tgt.astype(np.float64), wa.init_T, a.points, n_all, a.iters)
         cpu_baseline = {"value": v, "unit": "iterations/s", "cores": 1, "kind": "port",
                         "sample": f"{n} pairs of the C4 distribution ({a.points}x{a.points} planar), {a.iters} forced iterations each, "
                                   f"oracle KDTree port of modules/icp.py, {secs:.1f} s",
-                        "all_cores_value": vall, "all_cores": cores, "cpu_model": _cpu_model()}
+                        "all_cores_value": vall, "all_cores": cores, "all_cores_pool_workers_seen": workers,
+                        "all_cores_sample": f"{n_all} pairs over a warm fork pool of {cores} processes (pool start-up outside the clock)", "cpu_model": _cpu_model()}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -315,6 +343,9 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+        if use_dist:                                               # what the collective delivered: every rank's block, this rank's in its place
+            assert gathered.shape[0] == world * S and torch.equal(gathered[rank * S:(rank + 1) * S], out_T), "all-gather of the relative poses"
+            assert bool(torch.isfinite(gathered).all())
         iters_done = int(out_it.sum().item())
         assert iters_done == S * I, (iters_done, S * I)
         total_iters = world * S * I * a.steps
@@ -333,7 +364,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C4 synthetic batch: {S} scan pairs per GPU x {P}x{P} planar points, {I} forced ICP iterations per pair",
                        "pairs_per_gpu": S, "points": P, "iterations": I, "sharding": f"independent pairs over {world} GPU(s), all-gather of poses", "search": "all pairs (LSLAM_ICP_ALL_PAIRS)",
-                       "precision": "float32 points in HBM (lslam_icp_batch_dev); the float64-exact mode is timed beside it (float64_exact_mode)"},
+                       "precision": "`value` is the float32 mode (float32 points in HBM, lslam_icp_batch_dev: exact float32 nearest neighbours, float64 moments and solve); "
+                                    "the float64-exact mode — the reference's arithmetic, what the Python surface runs for float64 arrays — has its own roofline objects under float64_exact_mode"},
             "scan_pairs_per_sec": world * S * a.steps / dt,
             "pair_evals_per_sec": world * pair_evals_per_launch * a.steps / dt,
             "roofline": {"kernel": headline_kernel(S, P), "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS,
@@ -367,11 +399,14 @@ def main():
                                 oT2.data_ptr(), out_err.data_ptr(), out_it.data_ptr(), None, epsilon=0.0,
                                 max_iters=I - 1, stopping_thresh=0.0, stream=stream)
             ms_p = _time(torch, step_auto, 2, a.steps)
-            result["default_search_strategy"] = {"what": "same workload, search strategy left to the library (flags = 0): Morton-sorted clouds + exact box pruning "
-                                                         "(icp_sort_kernel + icp_pruned_kernel), identical correspondences and iteration counts",
+            ev_p = _time_events(torch, step_auto, 1, a.steps)
+            result["default_search_strategy"] = {"what": "same workload, search strategy left to the library (flags = 0): spatially ordered clouds + exact box pruning in the task-queue kernel "
+                                                         "(icp_sort_kernel + icp_queue_kernel; sources keep their match while a proof allows it), identical correspondences and iteration counts",
                                                  "ms_per_step": ms_p, "icp_iterations_per_sec": S * I / (ms_p * 1e-3),
                                                  "speedup_vs_all_pairs_sweep": (dt / a.steps * 1e3) / ms_p,
-                                                 "max_abs_T_difference": float((oT2 - out_T).abs().max().item())}
+                                                 "max_abs_T_difference": float((oT2 - out_T).abs().max().item()),
+                                                 "roofline": kernel_roofline("c4_default_search_strategy", "icp_queue_kernel<false,true>", ev_p, pair_evals_per_launch, 5,
+                                                                             "event time covers icp_sort_kernel + icp_queue_kernel; exact pruning + certificates: the N x M pair evaluations are what the launch is equivalent to, not what it executes")}
         if rank == 0 and world == 1:
             # float64-exact mode (what run_icp / poses_from_scan_matching use): the same clouds also resident in float64; near
             # ties of the float32 search decided on them, moments from them — results equal to the reference's float64 search
@@ -383,12 +418,18 @@ def main():
                                 stopping_thresh=0.0, stream=stream, prune=prune, d_src64=src64.data_ptr(), d_tgt64=tgt64.data_ptr())
             ms_f64_default = _time(torch, lambda: step_f64(None), 1, max(2, a.steps // 2))
             d_default = float((oT4 - oT2).abs().max().item())
+            ev_f64_default = _time_events(torch, lambda: step_f64(None), 0, max(2, a.steps // 2))
             ms_f64_all = _time(torch, lambda: step_f64(False), 1, 2)
+            ev_f64_all = _time_events(torch, lambda: step_f64(False), 0, 2)
             result["float64_exact_mode"] = {"what": "same workload with the float64 clouds beside the float32 ones (lslam_icp_batch_dev64): correspondences of a float64 search, moments from the float64 points",
                                             "ms_per_step_default_strategy": ms_f64_default, "ms_per_step_all_pairs": ms_f64_all,
                                             "cost_vs_float32_default_strategy": ms_f64_default / result["default_search_strategy"]["ms_per_step"],
                                             "cost_vs_float32_all_pairs": ms_f64_all / (dt / a.steps * 1e3),
                                             "max_abs_T_difference_to_float32_mode": d_default,
+                                            "roofline_all_pairs": kernel_roofline("c4_float64_exact_all_pairs", "icp_batch_filter_kernel<2,4,true>", ev_f64_all, pair_evals_per_launch, 5,
+                                                                                  "the headline's sweep with near ties decided and moments accumulated on the float64 points (kept on chip as int32 residuals beside the float32 copies); 4 points per lane: the 8-point build of this mode has no LDS left for the residuals (DESIGN.md 3.1d)"),
+                                            "roofline_default_strategy": kernel_roofline("c4_float64_exact_default", "icp_queue_kernel<true,true>", ev_f64_default, pair_evals_per_launch, 5,
+                                                                                         "icp_sort_kernel + icp_queue_kernel in float64-exact mode: one problem per CU (145 KB of LDS: float64 sources, float32 targets + residuals)"),
                                             "note": "the synthetic clouds are float32-representable, so both modes see the same points; the difference is the float32 recipe's rounding of near ties"}
             del src64, tgt64
         if rank == 0 and world == 1 and a.natural:
@@ -511,7 +552,7 @@ def other_config(name, a, torch, device, stream, timed):
         return {"workload": "OGM build_map: 4956 scans of the C3 sequence into a 1201x1201 grid (res 0.05), host arrays in (PCIe included)",
                 "seconds": dt, "seconds_first_call": first_s, "scans_per_sec": len(seq.z_ts) / dt, "rays_per_sec": rays / dt,
                 "cell_updates_per_sec": cells / k * len(seq.z_ts) / dt, "cell_updates_per_scan": cells / k,
-                "roofline_note": "no scattered HBM access: ray records -> per-(scan, 64x64 tile) LDS accumulation -> coalesced int16 count planes -> per-cell apply in scan order; tile kernel bound by the LDS walk, apply kernel by its float64 update chain; see DESIGN.md 3.4 and profiles/r01/bench_default_kernel_stats.csv",
+                "roofline": ogm_roofline(cells / k * len(seq.z_ts)),
                 "cpu_port_seconds_per_scan": cpu_s, "cpu_port_extrapolated_seconds": cpu_s * len(seq.z_ts),
                 "speedup_vs_cpu_port_1core": cpu_s * len(seq.z_ts) / dt,
                 "logodds_equal_to_oracle_on_sample": bool(np.array_equal(g2.grid_map_log_odds, o.grid_map_log_odds))}
@@ -605,8 +646,10 @@ def other_config(name, a, torch, device, stream, timed):
                             "frac": it * 1e10 * 8 / (ms * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
                             "hbm_compulsory_bytes_per_iteration": 12 * 2 * 100000 + 4 * 100000,
                             "note": "8 algorithmic flop per 3-D pair evaluation (expanded-form filter sweep: 3 v_fma + a minimum per pair, exact recipe on the chunks within the rounding bound); whole iteration (3 launches) timed, not the search kernel alone"},
-               "default_search_strategy": {"what": "same 20 iterations, strategy left to the library (pruning above 1e9 pair evaluations per iteration: Morton sort + box hierarchy, exact results; the sort is inside the timed call)",
-                          "ms": ms_p, "speedup": ms / ms_p, "max_abs_T_difference": float(np.abs(res["p"][0] - T).max())},
+               "default_search_strategy": {"what": "same 20 iterations, strategy left to the library (pruning above 1e9 pair evaluations per iteration: Hilbert sort + box hierarchy, exact results; the sort is inside the timed call)",
+                          "ms": ms_p, "speedup": ms / ms_p, "max_abs_T_difference": float(np.abs(res["p"][0] - T).max()),
+                          "roofline": kernel_roofline("c5_default_search_strategy", "nn_pruned_kernel<3,1,false>", ms_p, it * 1e10, 8,
+                                                      "whole call (sort, tree build, 20 x search + moments + solve launches, host polls) over the 20 x 1e10 pair evaluations it is equivalent to; the search kernel is divergent-traversal latency bound")},
                "pose_err_vs_truth": float(np.abs(T - T_true).max())}
         s64, t64 = s.to(torch.float64), t.to(torch.float64)
         def run64():
@@ -655,6 +698,10 @@ def other_config(name, a, torch, device, stream, timed):
         kern64_ms = _time(torch, lambda: resident(True), 2, 8)
         assert int(oi.sum().item()) == int(info.iterations.sum())
         kern32_ms = _time(torch, lambda: resident(False), 2, 8)
+        npts = np.diff(off).astype(np.float64)
+        evals = float(np.sum(info.iterations.astype(np.float64) * npts[1:] * npts[:-1]))      # the N x M pair evaluations this sequence is equivalent to
+        ev64 = _time_events(torch, lambda: resident(True), 1, 8)
+        ev32 = _time_events(torch, lambda: resident(False), 1, 8)
         # CPU baseline on a bounded sample of the same sequence (oracle KDTree port = reference algorithm)
         from oracle import se2_oracle
         n = 400
@@ -664,13 +711,33 @@ def other_config(name, a, torch, device, stream, timed):
         same = int(np.sum(info.iterations[:n] == it_cpu))
         out = {"workload": "C3 dataset-20-like sequence: 4955 consecutive scan pairs (650-1081 pts), natural convergence, host arrays in/out (PCIe + chain included)",
                "stage_seconds": stage_s, "stage_seconds_first_call": first_s, "stage_seconds_float32_scans": stage32_s,
-               "kernel_seconds_scans_resident": kern64_ms * 1e-3, "kernel_seconds_scans_resident_float32": kern32_ms * 1e-3, "iteration_counts_differ_float32_vs_float64_exact": int(np.sum(info.iterations != info32.iterations)),
+               "kernel_seconds_scans_resident": kern64_ms * 1e-3, "kernel_seconds_scans_resident_float32": kern32_ms * 1e-3,
+               "roofline": kernel_roofline("c3_float64_exact", "icp_queue_kernel<true,false>", ev64, evals, 5,
+                                           "icp_sort_kernel (order test + copies) + icp_queue_kernel over the 4955 LiDAR-sized pairs to natural convergence, float64-exact mode (what the Python surface runs); exact pruning: equivalent pair evaluations"),
+               "roofline_float32": kernel_roofline("c3_float32", "icp_queue_kernel<false,false>", ev32, evals, 5, "same sequence, float32 scans"),
+               "iteration_counts_differ_float32_vs_float64_exact": int(np.sum(info.iterations != info32.iterations)),
                "max_rel_pose_difference_float32_vs_float64_exact": float(np.abs(rel - rel32).max()),
                "scan_pairs_per_sec": 4955 / stage_s, "total_iterations": int(info.iterations.sum()),
                "cpu_port_seconds_per_pair": cpu_s / n, "cpu_port_extrapolated_seconds": cpu_s / n * 4955,
                "speedup_vs_cpu_port_1core": (cpu_s / n * 4955) / stage_s, "iteration_counts_equal_on_sample": f"{same}/{n}",
                "synth_seconds": gen_s, "final_pose": poses[-1].tolist()}
     return out
+
+
+def ogm_roofline(cell_updates):
+    """the tile kernel against the integer-VALU issue rate of the device (43 T lane-ops/s: profiles/r01/valu_probe.txt): figures from the
+    committed PMC pass of `bench.py --workload ogm` while it matches these sources"""
+    prof = profile_figures("ogm", "ogm_tile_kernel<short>")
+    lane_ops = prof.get("valu_lane_ops_per_launch")
+    ms = prof.get("kernel_ms_under_pmc")
+    ach = (lane_ops / (ms * 1e-3) / 1e12) if (lane_ops and ms) else None
+    return {"kernel": "ogm_tile_kernel<short> (+ ogm_apply_kernel<short> per group of 128 scans)", "bound": "valu-int", "achieved": ach, "peak": 43.0, "unit": "T lane-ops/s",
+            "frac": (ach / 43.0) if ach else None, "kernel_ms": ms, "traffic": prof.get("hbm_bytes_per_launch"),
+            "lane_instructions_per_cell_update": (lane_ops * 39 / cell_updates) if lane_ops else None,
+            "stale_profile": prof.get("stale_profile"), "profile": prof.get("source"),
+            "note": "per launch = one group of 128 scans (39 groups per build_map); no scattered HBM access: ray records -> per-(scan, 64x64 tile) LDS accumulation -> coalesced int16 count "
+                    "planes -> per-cell apply in scan order.  Lanes-to-cells variants of the tile kernel were built and measured in round 4 (126 us flattened, 71 us in pieces of 16 cells, against 53 us "
+                    "for one ray per lane): DESIGN.md 3.4"}
 
 
 def _warm_gpu(seconds=0.25):
@@ -688,6 +755,19 @@ def _wall(fn):
     t0 = time.perf_counter()
     fn()
     return time.perf_counter() - t0
+
+
+def _time_events(torch, fn, warm, reps):
+    """average HIP-event time of fn's launches on torch's current stream (the stream the library is handed), in ms"""
+    _warm_gpu()
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in ev:
+        e0.record(); fn(); e1.record()
+    torch.cuda.synchronize()
+    return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
 
 
 def _time(torch, fn, warm, reps):
