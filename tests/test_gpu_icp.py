@@ -1171,3 +1171,66 @@ def test_release_thread_resources_and_continue(icp, prec):
     one_again = icp.run_icp(clouds[0], clouds[1], epsilon=1e-3)
     assert np.array_equal(first.T, again.T) and np.array_equal(first.iterations, again.iterations)
     assert np.array_equal(one, one_again)
+
+
+# ---- the task-queue kernel (csrc/lslam_icp_queue.hip): slots, tasks and matches kept on a proof ------------------------------------
+@pytest.mark.parametrize("knobs", [{}, {"LSLAM_ICP_QUEUE_CERTIFY": "1"}, {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_Q": "1", "LSLAM_ICP_QUEUE_WAVES": "3", "LSLAM_ICP_QUEUE_G": "5"},
+                                   {"LSLAM_ICP_QUEUE_CERTIFY": "0", "LSLAM_ICP_QUEUE_Q": "2", "LSLAM_ICP_QUEUE_WAVES": "16"}, {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_ECAP": "4.0"},
+                                   {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_LEAN_BELOW": "99"}])
+def test_task_queue_kernel_gives_the_all_pairs_answers(icp, prec, knobs, monkeypatch):
+    """ragged planar batch from one point to 4096 per cloud — more problems than a CU has slots, tiny and large ones mixed, duplicates, a
+    lattice, motions far from the start, many forced iterations (so that most sources hold a certificate most of the time), the normalised
+    error's bounding box — through the pruned path in several geometries (slots, waves, slabs per task, certificates forced on / off, a reach
+    extension far beyond its default cap, sources read from memory instead of LDS): identical correspondences and iteration counts as the
+    all-pairs sweep, T and error to float64 summation order"""
+    from lidar_slam_amd.batch import icp_batch
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(77)
+    sizes = [(1, 1), (3, 70), (64, 64), (65, 17), (700, 1081), (1081, 650), (2048, 2048), (2100, 3000), (4096, 4096), (129, 4000), (3000, 40)] + [(900 + 7 * k, 1000 - 5 * k) for k in range(12)]
+    srcs, tgts, inits = [], [], []
+    for n, m in sizes:
+        s, t = _random_problem(rng, 2, n, m, spread=rng.uniform(0.5, 15.0))
+        if m > 40:
+            t[m // 2] = t[3]                                  # an exact duplicate: lowest index wins
+        srcs.append(s); tgts.append(t)
+        th = rng.uniform(-0.3, 0.3)
+        T0 = np.eye(4); T0[:2, :2] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]; T0[:2, 3] = rng.normal(0, 0.3, 2)
+        inits.append(T0)
+    gx, gy = np.meshgrid(np.arange(40.0), np.arange(30.0))                       # a lattice: massive exact ties, again and again
+    lattice = np.column_stack((gx.ravel(), gy.ravel()))
+    srcs.append(lattice[::2] + [0.5, 0.5]); tgts.append(lattice); inits.append(np.eye(4))
+    fs, so = prec.pack(srcs)
+    ft, to = prec.pack(tgts)
+    I = np.stack(inits)
+    for kw in (dict(epsilon=0.0, stopping_thresh=0.0, max_iters=29), dict(epsilon=1e-3, normalize_error=True), dict(epsilon=1e-6, stopping_thresh=1e-9, max_iters=60)):
+        a = icp_batch(fs, so, ft, to, I, return_correspondences=True, prune=False, **kw)
+        b = icp_batch(fs, so, ft, to, I, return_correspondences=True, prune=True, **kw)
+        np.testing.assert_array_equal(b.iterations, a.iterations)
+        np.testing.assert_array_equal(b.correspondences, a.correspondences)
+        ok = np.isfinite(a.T).all(axis=(1, 2))
+        np.testing.assert_allclose(b.T[ok], a.T[ok], atol=1e-9)
+        np.testing.assert_allclose(b.error[ok], a.error[ok], rtol=1e-9, atol=1e-12)
+
+
+def test_task_queue_kernel_is_bitwise_reproducible_and_batch_independent(icp, prec):
+    """the same pairs solved twice, alone, and in the middle of another batch: every bit of T, error and iteration count equal — the
+    grouping of the float64 partial sums depends on a problem's size only (what the sharded driver relies on)"""
+    from lidar_slam_amd.batch import icp_batch
+    rng = np.random.default_rng(5)
+    srcs, tgts = [], []
+    for n, m in [(1081, 1000), (2600, 2300), (777, 800), (4096, 4096), (300, 1081)]:
+        s, t = _random_problem(rng, 2, n, m, spread=8.0)
+        srcs.append(s); tgts.append(t)
+    kw = dict(epsilon=1e-4, prune=True)
+    def solve(idx):
+        fs, so = prec.pack([srcs[i] for i in idx]); ft, to = prec.pack([tgts[i] for i in idx])
+        return icp_batch(fs, so, ft, to, np.tile(np.eye(4), (len(idx), 1, 1)), **kw)
+    whole, again = solve(range(5)), solve(range(5))
+    assert np.array_equal(whole.T, again.T) and np.array_equal(whole.error, again.error)
+    for i in range(5):
+        alone = solve([i])
+        assert np.array_equal(alone.T[0], whole.T[i]) and alone.error[0] == whole.error[i] and alone.iterations[0] == whole.iterations[i], i
+    mixed = solve([3, 0, 0, 4, 1, 2, 2])
+    for pos, i in enumerate([3, 0, 0, 4, 1, 2, 2]):
+        assert np.array_equal(mixed.T[pos], whole.T[i]), (pos, i)
