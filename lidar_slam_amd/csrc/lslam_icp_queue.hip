@@ -224,6 +224,9 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     const int most = nslabs > 32 ? 8 : 4;
     return fill < 2 ? 2 : (fill > most ? most : fill);
   };
+#ifndef QEXP_SLEEP
+#define QEXP_SLEEP 8
+#endif
 #ifndef QEXP_MOM
 #define QEXP_MOM 20
 #endif
@@ -808,7 +811,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       if (lane == 0) { __hip_atomic_store(sh_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicAdd(&lay.queue[1], 1u); }
       break;
     }
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(QEXP_SLEEP);
 #ifdef LSLAM_QUEUE_PROFILE
     if (__any(lane < Q && st_ == 0)) QUEUE_MARK(5); else QUEUE_MARK(4);       // [5]: idle while the workgroup's slots are draining (the queue is exhausted)
 #endif
@@ -876,7 +879,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   };
   size_t slot = layout(true);
   int Q = slots_for(slot);
-  const int lean_below = env_int("LSLAM_ICP_QUEUE_LEAN_BELOW", f64 ? 0 : 2);      // sources out of LDS when fewer slots than this fit with them
+  const int lean_below = env_int("LSLAM_ICP_QUEUE_LEAN_BELOW", f64 ? 6 : 2);      // sources out of LDS when fewer slots than this fit with them
   if (Q < lean_below && env_int("LSLAM_ICP_QUEUE_SRC_LDS", 0) == 0) {
     const size_t lean = layout(false);
     if (slots_for(lean) > Q) { slot = lean; Q = slots_for(lean); } else slot = layout(true);
@@ -893,6 +896,9 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
     if (q_forced > 0 && q_forced < Q) Q = q_forced;
   }
   if (Q * (nslabs > 0 ? nslabs : 1) < W) W = Q * (nslabs > 0 ? nslabs : 1);      // no more waves than tasks can ever be open
+  // one slot per CU (a 4096-point problem in float64-exact mode): its rounds of 8–16 tasks do not feed 16 waves, and the idle ones poll
+  // the LDS the working ones read (C4 float64-exact: 11.9 against 12.6 ms)
+  if (Q == 1 && certify && W > 8 && !getenv("LSLAM_ICP_QUEUE_WAVES")) W = 8;
   lay.slot_bytes = (uint32_t)slot;
   lay.ctl_bytes = (uint32_t)up((size_t)Q * kQCtlBytes + 64 + 128 + (size_t)kIcpBatchMaxWaves * kWave * sizeof(uint16_t));
   lay.Q = Q;
