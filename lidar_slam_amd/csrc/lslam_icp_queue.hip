@@ -25,7 +25,7 @@
 // Iterations after the first do not search every source again.  A search leaves, per source, a MARGIN: half the gap between
 // its nearest target and a proven lower bound on the distance to every other target (the second smallest distance evaluated, and
 // the reach beyond which chunks were skipped — extended by E for that purpose), minus the rounding of the positions.  Every later
-// iteration subtracts a bound on how far the new transform moved the source (‖ΔR‖_F·|p|max + |Δt| of its slab); while the margin
+// iteration subtracts a bound on how far the new transform moved the source (‖ΔR‖₂·|p|max + |Δt| of its slab); while the margin
 // stays positive the nearest target cannot have changed — by the triangle inequality, with the float32 recipe's rounding and in
 // float64-exact mode the near-tie window inside the margin — and the source keeps its match.  The sources of a task whose margin
 // ran out are gathered, 64 at a time, and searched as before.  Exactness is untouched: a source is skipped only on a proof.
@@ -387,13 +387,15 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     step_parts(mo, true, R, pb, qb);
     const double told = c->T[lane & 15];
     const double tn = step_times_prev_lane(R, pb, qb, c->T, rows + (size_t)kQRows * RS, lane);   // element `lane` of T_step·T_prev
-    // how far the new transform can move a source: ‖ΔR‖_F·|p| + |Δt| (Frobenius ≥ spectral norm), rounded up
+    // how far the new transform can move a source p: ‖ΔR‖₂·|p| + |Δt|, rounded up
     float stepR = INFINITY, stepT = INFINITY;
     if constexpr (CERT) {
       const double dl = tn - told;
       auto at = [&](int k) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dl), k), __builtin_amdgcn_readlane(__double2loint(dl), k)); };
       const double d00 = at(0), d01 = at(1), d03 = at(3), d10 = at(4), d11 = at(5), d13 = at(7);
-      stepR = (float)(sqrt(d00 * d00 + d01 * d01 + d10 * d10 + d11 * d11) * 1.000001) + 1e-30f;
+      // the largest singular value of the 2 x 2 block ΔR (for a pure rotation step: 2 sin(Δθ/2), a factor √2 below the Frobenius norm)
+      const double f2 = d00 * d00 + d01 * d01 + d10 * d10 + d11 * d11, g1 = d00 * d00 + d01 * d01 - d10 * d10 - d11 * d11, g2 = d00 * d10 + d01 * d11;
+      stepR = (float)(sqrt(0.5 * (f2 + sqrt(g1 * g1 + 4.0 * g2 * g2))) * 1.000001) + 1e-30f;
       stepT = (float)(sqrt(d03 * d03 + d13 * d13) * 1.000001) + 1e-30f;
     }
     const double err = error_from_moments(mo, box);
