@@ -81,6 +81,7 @@ __device__ inline void bitonic_sort(unsigned* keys, int len) {
 // clouds through HBM (three passes + a gather of 8 bytes per cache line) and spent 78 barrier-separated steps per sort.  A cell
 // holding more than kSortCellMax points (collapsed or very uneven clouds) sends that cloud to the bitonic sort.
 constexpr int kSortCellMax = 48;
+template <int kSortThreads>       // 256 lanes for LiDAR-sized clouds (seven workgroups per CU), 512 from 2048 points per cloud (C4: 0.70 -> 0.50 ms)
 __global__ void __launch_bounds__(kSortThreads)
 icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, int curve, int cap, int cur_words) {
   // LDS sized by the launch for the batch's largest cloud (cap points, cur_words counters ≥ cells + 1 and ≥ len_pow2 keys):
@@ -793,11 +794,16 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   if (curve >= 1) g_max *= 2;
   const int cur_words = ((g_max * g_max + 64 > len ? g_max * g_max + 64 : len) + 3) & ~3;
   const size_t sort_lds = sizeof(float2) * (size_t)cap + sizeof(unsigned) * (size_t)cur_words + 2 * sizeof(uint16_t) * (size_t)cap;
+  auto sort = [&](auto kernel, int threads) -> hipError_t {
+    hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
+    if (ee != hipSuccess) return ee;
+    hipLaunchKernelGGL(kernel, dim3(S), dim3(threads), sort_lds, stream, a, sc, len, keep, curve, cap, cur_words);
+    return hipSuccess;
+  };
   {
-    hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(icp_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
+    const hipError_t ee = big >= 2048 ? sort(icp_sort_kernel<512>, 512) : sort(icp_sort_kernel<256>, 256);
     if (ee != hipSuccess) return ee;
   }
-  hipLaunchKernelGGL(icp_sort_kernel, dim3(S), dim3(kSortThreads), sort_lds, stream, a, sc, len, keep, curve, cap, cur_words);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // 2. iterate: the task-queue kernel (lslam_icp_queue.hip: problems in LDS slots, waves draw tasks, no barriers; from 2048 points

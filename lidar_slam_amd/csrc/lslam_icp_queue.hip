@@ -25,7 +25,7 @@
 // Iterations after the first do not search every source again.  A search leaves, per source, a MARGIN: half the gap between
 // its nearest target and a proven lower bound on the distance to every other target (the second smallest distance evaluated, and
 // the reach beyond which chunks were skipped — extended by E for that purpose), minus the rounding of the positions.  Every later
-// iteration subtracts a bound on how far the new transform moved the source (‖ΔR‖₂·|p|max + |Δt| of its slab); while the margin
+// iteration subtracts a bound on how far the new transform moved the source (‖ΔR‖₂·|p|max + |Δt|, |p|max over the cloud); while the margin
 // stays positive the nearest target cannot have changed — by the triangle inequality, with the float32 recipe's rounding and in
 // float64-exact mode the near-tie window inside the margin — and the source keeps its match.  The sources of a task whose margin
 // ran out are gathered, 64 at a time, and searched as before.  Exactness is untouched: a source is skipped only on a proof.
@@ -57,7 +57,10 @@ namespace lslam {
 constexpr int kQCtlBytes = 256;
 constexpr long long kQTimeoutTicks = 400000000ll;      // 4 s of the 100 MHz wall clock
 constexpr int kQRec = kPruneChunk * 8 + 16;            // bytes per chunk record: 16 targets + the chunk's box
-constexpr int kQRows = 16;                             // rows of float64 partial sums per slot (moment_slabs: one row up to 20 slabs, 8 slabs per row up to 64, 16 up to 128)
+// rows of float64 partial sums per slot and slabs per row above 20 slabs (moment_slabs): float32 mode 4 rows of 16 (32 above 64 slabs) — a
+// 4096-point problem then leaves room for a third slot per CU —, float64-exact mode 8 rows of 8 (16): its one 4096-point problem per CU needs the finer tasks
+constexpr int queue_rows(bool f64) { return f64 ? 8 : 4; }
+constexpr int queue_row_slabs(bool f64) { return f64 ? 8 : 16; }
 constexpr float kQExtend = 4.f;                        // E = kQExtend × the last step's largest displacement (capped): what a search pays for later certificates
 constexpr float kQPad = 1.0e18f;                       // x of the padding targets (times 1 + slot/16), y = 0
 constexpr float kQFarD2 = 1.0e35f;                     // a best distance beyond this is not trusted (padding, overflow): exhaustive pass
@@ -230,10 +233,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
 #ifndef QEXP_MOM
 #define QEXP_MOM 20
 #endif
-#ifndef QEXP_MOMBIG
-#define QEXP_MOMBIG 8
-#endif
-  auto moment_slabs = [&](int nslabs) -> int { return nslabs <= QEXP_MOM ? (nslabs > 0 ? nslabs : 1) : (nslabs <= 64 ? QEXP_MOMBIG : 2 * QEXP_MOMBIG); };
+  auto moment_slabs = [&](int nslabs) -> int { return nslabs <= QEXP_MOM ? (nslabs > 0 ? nslabs : 1) : (nslabs <= 64 ? queue_row_slabs(F64) : 2 * queue_row_slabs(F64)); };
   auto moment_tasks = [&](int nslabs) -> int { return nslabs > 0 ? (nslabs + moment_slabs(nslabs) - 1) / moment_slabs(nslabs) : 1; };
 
   // ---- one wave: draw the next problem and stage it into slot q (or mark the slot empty for good) ----
@@ -247,7 +247,6 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       return;
     }
     unsigned char* base = slot_of(q);
-    float* slab_pmax = reinterpret_cast<float*>(base + lay.slab_off);
     int2* tdelta = reinterpret_cast<int2*>(base + lay.tdelta_off);
     float2* sh_src = reinterpret_cast<float2*>(base + lay.src_off);
     double2* sh_src64 = reinterpret_cast<double2*>(base + lay.src_off);
@@ -297,21 +296,16 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       if constexpr (CERT) sh_margin[i] = 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    // the largest |p| of every slab of 64 sources: what a change of the transform can move them by
-    for (int sl = 0; (F64 || CERT) && sl < nslabs; ++sl) {
-      const int i = sl * kWave + lane;
-      float p2 = 0.f;
-      if (i < n) {
+    // the largest |p| of the cloud: what a change of the transform can move a source by (margins), the near-tie window (float64-exact mode)
+    if constexpr (F64 || CERT) {
+      for (int i = lane; i < n; i += kWave) {
         float vx, vy;
         if constexpr (F64) { const double2 pd = load_source64(src_lds, sh_src64, sc.src64_sorted + ss, i); vx = (float)pd.x; vy = (float)pd.y; }
         else { const float2 v = load_source(src_lds, sh_src, sc.src_sorted + ss, i); vx = v.x; vy = v.y; }
-        p2 = __builtin_fmaf(vy, vy, vx * vx);
+        smax = fmaxf(smax, __builtin_fmaf(vy, vy, vx * vx));
       }
-      p2 = wave_max_dpp(p2);
-      smax = fmaxf(smax, p2);
-      if (lane == 0) slab_pmax[sl] = sqrtf(p2) * 1.000001f + 1e-30f;
+      smax = wave_max_dpp(smax);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     for (int cidx = lane; cidx < nchunks; cidx += kWave) {     // boxes over the real points only
       float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
       const float2* rec = reinterpret_cast<const float2*>(base + (size_t)cidx * kQRec);
@@ -348,7 +342,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   auto finish = [&](int q) {
     QueueCtl* c = ctl_of(q);
     unsigned char* base = slot_of(q);
-    double* rows = reinterpret_cast<double*>(base + lay.rows_off);       // [kQRows][RS] + 16 doubles of scratch
+    double* rows = reinterpret_cast<double*>(base + lay.rows_off);       // [queue_rows][RS]
     const int n = lds_load_i32(&c->n), nslabs = lds_load_i32(&c->nslabs);
     const int ntasks = moment_tasks(nslabs);                   // rows of partial sums
     double col;
@@ -386,7 +380,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     double R[9], pb[3], qb[3];
     step_parts(mo, true, R, pb, qb);
     const double told = c->T[lane & 15];
-    const double tn = step_times_prev_lane(R, pb, qb, c->T, rows + (size_t)kQRows * RS, lane);   // element `lane` of T_step·T_prev
+    const double tn = step_times_prev_lane(R, pb, qb, c->T, rows, lane);   // element `lane` of T_step·T_prev (the rows are consumed: their first 16 doubles serve as its scratch)
     // how far the new transform can move a source p: ‖ΔR‖₂·|p| + |Δt|, rounded up
     float stepR = INFINITY, stepT = INFINITY;
     if constexpr (CERT) {
@@ -435,7 +429,6 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   auto search_task = [&](int q, int t) {
     QueueCtl* c = ctl_of(q);
     unsigned char* base = slot_of(q);
-    const float* slab_pmax = reinterpret_cast<const float*>(base + lay.slab_off);
     const float2* sh_src = reinterpret_cast<const float2*>(base + lay.src_off);
     const double2* sh_src64 = reinterpret_cast<const double2*>(base + lay.src_off);
     uint16_t* sh_prev = reinterpret_cast<uint16_t*>(base + lay.prev_off);
@@ -663,7 +656,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       const bool owns = slab < slab_hi && i < n;
       bool need = owns;
       if (CERT && stepR < INFINITY && slab < slab_hi) {
-        const float step = (__builtin_fmaf(stepR, slab_pmax[slab], stepT)) * 1.00002f;
+        const float step = (__builtin_fmaf(stepR, CTL_FLOAT(cw, Rs), stepT)) * 1.00002f;      // every source of the cloud moved by less
         if (owns) {
           const float left = (float)__builtin_bit_cast(_Float16, sh_margin[i]) - step;
           need = !(left > 0.f);
@@ -859,24 +852,23 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   // slabs, and the margins cost a slot of LDS (C3: 0.72 -> 0.85 ms): from 2048 points per cloud by default.
   bool certify = max_src_n >= 2048 || max_tgt_n >= 2048;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_CERTIFY")) certify = atoi(e) != 0;
-  const int rows_cap = kQRows;
+  const int rows_cap = queue_rows(f64);
   lay.rows_cap = rows_cap;
   // a slot's layout; float32 sources live in LDS when two slots still fit a CU, else they are read from the sorted copy in memory
   // (once per search and once per moment task, coalesced: 4096-point problems then keep two slots per CU)
   auto layout = [&](bool src_in_lds) -> size_t {
     size_t off = (size_t)nchunks * kQRec;
-    lay.slab_off = (uint32_t)off; off += up((size_t)(nslabs > 0 ? nslabs : 1) * sizeof(float));
     lay.tdelta_off = (uint32_t)off; if (f64) off += (size_t)padded * sizeof(float2);
     lay.src_off = 0xffffffffu;
     if (src_in_lds) { lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * (f64 ? sizeof(double2) : sizeof(float2))); }
     lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));
     lay.margin_off = (uint32_t)off; if (certify) off += up((size_t)max_src_n * sizeof(uint16_t));
-    lay.rows_off = (uint32_t)off; off += sizeof(double) * ((size_t)rows_cap * RS + 16);
+    lay.rows_off = (uint32_t)off; off += sizeof(double) * (size_t)(rows_cap * RS > 16 ? rows_cap * RS : 16);
     return up(off);
   };
   auto slots_for = [&](size_t slot_bytes) -> int {
     int q = 0;
-    while (q < 16 && (size_t)(q + 1) * kQCtlBytes + 192 + 2048 + (size_t)(q + 1) * slot_bytes <= kLdsPerCu) ++q;
+    while (q < 16 && (size_t)(q + 1) * kQCtlBytes + 192 + 2048 + 16 + (size_t)(q + 1) * slot_bytes <= kLdsPerCu) ++q;
     return q;
   };
   size_t slot = layout(true);
@@ -905,7 +897,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   lay.ctl_bytes = (uint32_t)up((size_t)Q * kQCtlBytes + 64 + 128 + (size_t)kIcpBatchMaxWaves * kWave * sizeof(uint16_t));
   lay.Q = Q;
   lay.G = env_int("LSLAM_ICP_QUEUE_G", 0);                     // slabs per search task; 0: one, two for problems above 32 slabs
-  if (nslabs > kQRows * 2 * QEXP_MOMBIG) return hipErrorInvalidValue;
+  if (nslabs > queue_rows(f64) * 2 * queue_row_slabs(f64)) return hipErrorInvalidValue;
   lay.certify = certify ? 1 : 0;
   lay.ecap_frac = 0.25f;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_ECAP")) lay.ecap_frac = (float)atof(e);

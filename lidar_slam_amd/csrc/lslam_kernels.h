@@ -80,7 +80,7 @@ struct PruneScratch {                      // Morton-sorted copies: problem k ow
 // lslam_icp_queue.hip: byte offsets inside one LDS slot (the target tile is at 0), slots per workgroup, slabs per task
 struct QueueLayout {
   uint32_t slot_bytes, ctl_bytes;
-  uint32_t slab_off, tdelta_off, src_off, prev_off, margin_off, rows_off;      // the chunk records (16 targets + box each) start at 0; src_off = 0xffffffff: sources read from memory
+  uint32_t tdelta_off, src_off, prev_off, margin_off, rows_off;      // the chunk records (16 targets + box each) start at 0; src_off = 0xffffffff: sources read from memory
   int32_t certify;                                                 // keep matches on a proof instead of searching every source in every iteration
   float ecap_frac;                                                 // cap of the reach extension as a fraction of the targets' mean spacing
   int32_t Q, G, rows_cap;                                          // G = 0: task size chosen per problem and iteration

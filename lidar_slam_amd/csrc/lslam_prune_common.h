@@ -12,7 +12,6 @@ namespace lslam {
 #define LSLAM_PRUNE_CHUNK 16
 #endif
 constexpr int kPruneChunk = LSLAM_PRUNE_CHUNK;   // targets per box (8 was measured: see DESIGN §3.1b)
-constexpr int kSortThreads = 256;
 constexpr float kPruneSafety = 0.99999f;
 
 // the next float above a non-negative finite float (or +inf)
