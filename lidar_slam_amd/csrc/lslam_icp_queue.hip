@@ -398,10 +398,12 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     if (lane < 16) c->T[lane] = tn;
     QUEUE_MARK(2);
     if (!stop) {
-      const int G = search_group(nslabs, st.executed);
+      // from the second iteration on, with certificates: one round of fused tasks (a moment group's slabs searched, then its row)
+      const bool fuse = CERT && lay.fuse && moment_tasks(nslabs) > 1;
+      const int G = fuse ? moment_slabs(nslabs) : search_group(nslabs, st.executed);
       if (lane == 0) {
         c->stop = st; c->err = err; c->done_tasks = 0;
-        c->G = G; c->phase = 0;
+        c->G = G; c->phase = fuse ? 2 : 0;
         c->stepR = stepR; c->stepT = stepT;
         // the next searches extend their reach by E ≈ kQExtend × this step (the steps of a converging run shrink geometrically:
         // margins of E / 2 then outlast what is still to come); nothing while the steps exceed what E may cost
@@ -751,16 +753,24 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   auto run_task = [&](int q, int t, int ntasks) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     QueueCtl* c = ctl_of(q);
-    const int phase = lds_load_i32(&c->phase);
-    if (phase == 0) search_task(q, t); else moment_task(q, t);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    unsigned d = 0;
-    if (lane == 0) d = atomicAdd(&c->done_tasks, 1u) + 1u;
-    d = __builtin_amdgcn_readfirstlane(d);
-    if (d != (unsigned)ntasks) return;
-    if (lane == 0) close_slot(q);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (phase == 0) {
+    int phase = lds_load_i32(&c->phase);
+    // phase 2: FUSED tasks — the search of a moment group's slabs and then that group's row, in one task: once most sources keep
+    // their match the search round is a handful of cheap tasks, and a second round only adds its hand-offs to every iteration
+    const bool fused = phase == 2;
+    bool solo = false;                                         // the one moment task of a small problem, run by the wave that closed its search round
+    for (;;) {                                                 // (a loop so that each routine has one call site)
+      if (phase != 1) search_task(q, t);
+      if (phase != 0) moment_task(q, t);
+      if (!solo) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        unsigned d = 0;
+        if (lane == 0) d = atomicAdd(&c->done_tasks, 1u) + 1u;
+        d = __builtin_amdgcn_readfirstlane(d);
+        if (d != (unsigned)ntasks) return;
+        if (lane == 0) close_slot(q);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      if (phase != 0) break;
       const int nrows = moment_tasks(lds_load_i32(&c->nslabs));
       if (nrows > 1) {                                         // a large problem: its moments are a round of tasks as well
         if (lane == 0) { c->phase = 1; c->done_tasks = 0; }
@@ -768,8 +778,9 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         if (lane == 0) open_slot(q, nrows);
         return;
       }
-      moment_task(q, 0);
+      phase = 1; t = 0; solo = true;
     }
+    (void)fused;
     finish(q);
   };
 
@@ -893,12 +904,16 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   // one slot per CU (a 4096-point problem in float64-exact mode): its rounds of 8–16 tasks do not feed 16 waves, and the idle ones poll
   // the LDS the working ones read (C4 float64-exact: 11.9 against 12.6 ms)
   if (Q == 1 && certify && W > 8 && !getenv("LSLAM_ICP_QUEUE_WAVES")) W = 8;
+  // one slot per CU: a second round of tasks per iteration only adds hand-offs (C4 float64-exact 11.4 -> 10.7 ms); with three slots the
+  // fused tasks are too few and too coarse (5.7 -> 5.8 ms)
+  lay.fuse = env_int("LSLAM_ICP_QUEUE_FUSE", Q == 1 ? 1 : 0);
   lay.slot_bytes = (uint32_t)slot;
   lay.ctl_bytes = (uint32_t)up((size_t)Q * kQCtlBytes + 64 + 128 + (size_t)kIcpBatchMaxWaves * kWave * sizeof(uint16_t));
   lay.Q = Q;
   lay.G = env_int("LSLAM_ICP_QUEUE_G", 0);                     // slabs per search task; 0: one, two for problems above 32 slabs
   if (nslabs > queue_rows(f64) * 2 * queue_row_slabs(f64)) return hipErrorInvalidValue;
   lay.certify = certify ? 1 : 0;
+  lay.fuse = 0;                                                // set below, once the number of slots is known
   lay.ecap_frac = 0.25f;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_ECAP")) lay.ecap_frac = (float)atof(e);
   lay.queue = sc.queue;
