@@ -57,10 +57,13 @@ namespace lslam {
 constexpr int kQCtlBytes = 256;
 constexpr long long kQTimeoutTicks = 400000000ll;      // 4 s of the 100 MHz wall clock
 constexpr int kQRec = kPruneChunk * 8 + 16;            // bytes per chunk record: 16 targets + the chunk's box
+#ifndef QEXP_F64ROWS
+#define QEXP_F64ROWS 8
+#endif
 // rows of float64 partial sums per slot and slabs per row above 20 slabs (moment_slabs): float32 mode 4 rows of 16 (32 above 64 slabs) — a
 // 4096-point problem then leaves room for a third slot per CU —, float64-exact mode 8 rows of 8 (16): its one 4096-point problem per CU needs the finer tasks
-constexpr int queue_rows(bool f64) { return f64 ? 8 : 4; }
-constexpr int queue_row_slabs(bool f64) { return f64 ? 8 : 16; }
+constexpr int queue_rows(bool f64) { return f64 ? QEXP_F64ROWS : 4; }
+constexpr int queue_row_slabs(bool f64) { return f64 ? 64 / QEXP_F64ROWS : 16; }
 constexpr float kQExtend = 4.f;                        // E = kQExtend × the last step's largest displacement (capped): what a search pays for later certificates
 constexpr float kQPad = 1.0e18f;                       // x of the padding targets (times 1 + slot/16), y = 0
 constexpr float kQFarD2 = 1.0e35f;                     // a best distance beyond this is not trusted (padding, overflow): exhaustive pass
@@ -913,7 +916,6 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   lay.G = env_int("LSLAM_ICP_QUEUE_G", 0);                     // slabs per search task; 0: one, two for problems above 32 slabs
   if (nslabs > queue_rows(f64) * 2 * queue_row_slabs(f64)) return hipErrorInvalidValue;
   lay.certify = certify ? 1 : 0;
-  lay.fuse = 0;                                                // set below, once the number of slots is known
   lay.ecap_frac = 0.25f;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_ECAP")) lay.ecap_frac = (float)atof(e);
   lay.queue = sc.queue;
