@@ -164,6 +164,7 @@ struct PruneHolder {
     if (sc.src64_sorted) (void)hipFree(sc.src64_sorted);
     if (sc.tgt64_sorted) (void)hipFree(sc.tgt64_sorted);
     if (sc.queue) (void)hipFree(sc.queue);
+    if (sc.margins) (void)hipFree(sc.margins);
     sc = PruneScratch{}; cap_src = cap_tgt = cap_src64 = cap_tgt64 = 0; device = -1;
   }
   int ensure(int32_t S, int64_t max_src_n, int64_t max_tgt_n, bool f64) {
@@ -190,6 +191,14 @@ struct PruneHolder {
       LSLAM_HIP_TRY(hipMalloc(&sc.src64_sorted, sizeof(double2) * need_src));
       LSLAM_HIP_TRY(hipMalloc(&sc.tgt64_sorted, sizeof(double2) * need_tgt));
       cap_src64 = need_src; cap_tgt64 = need_tgt;
+    }
+    // … and the task-queue kernel's margins: at most 16 slots of kPruneMaxPoints sources per workgroup, one workgroup per CU
+    if (f64 && !sc.margins) {
+      int cus = 0;
+      LSLAM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      if (cus <= 0) cus = 256;
+      sc.margin_cap = (size_t)cus * 16 * (size_t)kPruneMaxPoints;
+      LSLAM_HIP_TRY(hipMalloc(&sc.margins, sizeof(uint16_t) * sc.margin_cap));
     }
     sc.src_stride = max_src_n; sc.tgt_stride = max_tgt_n;
     return LSLAM_OK;

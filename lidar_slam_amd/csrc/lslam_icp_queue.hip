@@ -201,7 +201,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   auto slot_of = [&](int q) { return smem + lay.ctl_bytes + (size_t)q * lay.slot_bytes; };
 #ifdef LSLAM_QUEUE_PROFILE
   unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime();
-  unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};             // searches of ≤ 64 sources, surviving boxes, list rounds, (point, chunk) list entries, sources visited, sources searched
+  unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [6] cycles inside search_points, [7] tasks run; searches of ≤ 64 sources, surviving boxes, list rounds, (point, chunk) list entries, sources visited, sources searched
 #define QUEUE_COUNT(k, v) do { cnt[k] += (v); } while (0)
 #else
 #define QUEUE_COUNT(k, v) do {} while (0)
@@ -236,8 +236,27 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
 #ifndef QEXP_MOM
 #define QEXP_MOM 20
 #endif
-  auto moment_slabs = [&](int nslabs) -> int { return nslabs <= QEXP_MOM ? (nslabs > 0 ? nslabs : 1) : (nslabs <= 64 ? queue_row_slabs(F64) : 2 * queue_row_slabs(F64)); };
+#ifndef QEXP_PAIR
+#define QEXP_PAIR (F64 ? 1 : 2)
+#endif
+  // Above QEXP_MOM slabs a row is the sum of QEXP_PAIR (1 or 2) tasks: each adds its partial sums into the zeroed row with LDS float64 atomics.
+  // 0 + a is a, and a + b is b + a to the bit, so which of the two arrives first cannot change the row; twice the tasks at the same LDS.
+  auto moment_slabs = [&](int nslabs) -> int { return nslabs <= QEXP_MOM ? (nslabs > 0 ? nslabs : 1) : (nslabs <= 64 ? queue_row_slabs(F64) : 2 * queue_row_slabs(F64)) / QEXP_PAIR; };
   auto moment_tasks = [&](int nslabs) -> int { return nslabs > 0 ? (nslabs + moment_slabs(nslabs) - 1) / moment_slabs(nslabs) : 1; };
+  auto moment_rows = [&](int nslabs) -> int { return nslabs <= QEXP_MOM ? 1 : (moment_tasks(nslabs) + QEXP_PAIR - 1) / QEXP_PAIR; };
+  // rows that tasks ADD into start from the neutral element (one wave; the caller publishes the stores with its release fence)
+  auto clear_rows = [&](unsigned char* base, int nslabs) {
+    if (QEXP_PAIR == 1 || nslabs <= QEXP_MOM) return;
+    double* rows = reinterpret_cast<double*>(base + lay.rows_off);
+    for (int k = lane; k < moment_rows(nslabs) * RS; k += kWave) { const int cl = k % RS; rows[k] = cl < 9 ? 0.0 : (cl < 11 ? (double)INFINITY : -(double)INFINITY); }
+  };
+
+  // margins: in LDS; in float64-exact mode (whose slot also holds the targets' float64 residuals) in this workgroup's rows of a scratch
+  // buffer in memory, read and written a slab at a time — the workgroup's waves share the CU's L1, workgroup-scope fences order them
+  auto margins_of = [&](int q, unsigned char* base) -> uint16_t* {
+    if constexpr (F64) return lay.margins + ((size_t)blockIdx.x * (size_t)Q + (size_t)q) * lay.margin_stride;
+    else return reinterpret_cast<uint16_t*>(base + lay.margin_off);
+  };
 
   // ---- one wave: draw the next problem and stage it into slot q (or mark the slot empty for good) ----
   auto refill = [&](int q) {
@@ -254,7 +273,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     float2* sh_src = reinterpret_cast<float2*>(base + lay.src_off);
     double2* sh_src64 = reinterpret_cast<double2*>(base + lay.src_off);
     uint16_t* sh_prev = reinterpret_cast<uint16_t*>(base + lay.prev_off);
-    uint16_t* sh_margin = reinterpret_cast<uint16_t*>(base + lay.margin_off);
+    uint16_t* sh_margin = margins_of(q, base);
     const bool src_lds = lay.src_off != 0xffffffffu;
     const int64_t s0 = args.src_off[p], t0 = args.tgt_off[p];
     const int n = (int)(args.src_off[p + 1] - s0), m = (int)(args.tgt_off[p + 1] - t0);
@@ -321,6 +340,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     if constexpr (F64 || CERT) tmax = wave_max_dpp(tmax);
     if constexpr (CERT) { bx0 = wave_min_dpp(bx0); by0 = wave_min_dpp(by0); bx1 = wave_max_dpp(bx1); by1 = wave_max_dpp(by1); }
     if (lane < 16) c->T[lane] = args.init_T[(int64_t)16 * p + lane];
+    clear_rows(base, nslabs);
     if (lane == 0) __hip_atomic_store(&states[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const int G = search_group(nslabs, 0);
     if (lane == 0) {
@@ -347,7 +367,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     unsigned char* base = slot_of(q);
     double* rows = reinterpret_cast<double*>(base + lay.rows_off);       // [queue_rows][RS]
     const int n = lds_load_i32(&c->n), nslabs = lds_load_i32(&c->nslabs);
-    const int ntasks = moment_tasks(nslabs);                   // rows of partial sums
+    const int ntasks = moment_rows(nslabs);                    // rows of partial sums
     double col;
     {
       const int cl = lane < RS ? lane : 0;
@@ -404,6 +424,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       // from the second iteration on, with certificates: one round of fused tasks (a moment group's slabs searched, then its row)
       const bool fuse = CERT && lay.fuse && moment_tasks(nslabs) > 1;
       const int G = fuse ? moment_slabs(nslabs) : search_group(nslabs, st.executed);
+      clear_rows(base, nslabs);
       if (lane == 0) {
         c->stop = st; c->err = err; c->done_tasks = 0;
         c->G = G; c->phase = fuse ? 2 : 0;
@@ -437,7 +458,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     const float2* sh_src = reinterpret_cast<const float2*>(base + lay.src_off);
     const double2* sh_src64 = reinterpret_cast<const double2*>(base + lay.src_off);
     uint16_t* sh_prev = reinterpret_cast<uint16_t*>(base + lay.prev_off);
-    uint16_t* sh_margin = reinterpret_cast<uint16_t*>(base + lay.margin_off);
+    uint16_t* sh_margin = margins_of(q, base);
     uint16_t* gathered = reinterpret_cast<uint16_t*>(smem + (size_t)Q * kQCtlBytes + 192) + wave * kWave;      // this wave's list of sources to search
     const bool src_lds = lay.src_off != 0xffffffffu;
     const int cw = ctl_load(c, lane);
@@ -656,28 +677,48 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       return;
     }
     int pending = 0;                                           // entries of `gathered`
+    unsigned needbits = 0u;                                    // bit k: this lane's source of slab (group start + k) must be searched
+    const float step = CERT ? (__builtin_fmaf(stepR, CTL_FLOAT(cw, Rs), stepT)) * 1.00002f : 0.f;      // every source of the cloud moved by less
     for (int slab = slab_lo; slab <= slab_hi; ++slab) {       // slab_hi: the trip that searches what is left in the list
       const int i = slab * kWave + lane;
       const bool owns = slab < slab_hi && i < n;
-      bool need = owns;
-      if (CERT && stepR < INFINITY && slab < slab_hi) {
-        const float step = (__builtin_fmaf(stepR, CTL_FLOAT(cw, Rs), stepT)) * 1.00002f;      // every source of the cloud moved by less
-        if (owns) {
-          const float left = (float)__builtin_bit_cast(_Float16, sh_margin[i]) - step;
-          need = !(left > 0.f);
-          if (!need) {
+      const int u = (slab - slab_lo) & 7;
+      if (u == 0 && slab < slab_hi) {
+        // the margins of eight slabs at a time: their loads in flight together, the updated ones written back
+        needbits = 0u;
+        uint16_t mv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int ii = (slab + k) * kWave + lane;
+          mv[k] = (stepR < INFINITY && slab + k < slab_hi && ii < n) ? sh_margin[ii] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int ii = (slab + k) * kWave + lane;
+          const bool ok = slab + k < slab_hi && ii < n;
+          const float left = (float)__builtin_bit_cast(_Float16, mv[k]) - step;
+          const bool keep = ok && stepR < INFINITY && left > 0.f;
+          if (keep) {
             const unsigned hb = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(left, 0.f));
-            sh_margin[i] = (uint16_t)(hb & 0xffffu);
+            sh_margin[ii] = (uint16_t)(hb & 0xffffu);
           }
+          needbits |= (ok && !keep) ? (1u << k) : 0u;
         }
       }
+      const bool need = owns && ((needbits >> u) & 1u) != 0u;
       const unsigned long long mask = __ballot(need);
       const int nneed = __builtin_popcountll(mask);
       QUEUE_COUNT(4, __builtin_popcountll(__ballot(owns)));
       QUEUE_COUNT(5, nneed);
       if (pending > 0 && (slab == slab_hi || pending + nneed > kWave)) {      // the list is full, or this was the last slab
         const int gi = lane < pending ? gathered[lane] : 0;
+#ifdef LSLAM_QUEUE_PROFILE
+        const unsigned long long sp0_ = __builtin_amdgcn_s_memtime();
+#endif
         search_points(gi, lane < pending);
+#ifdef LSLAM_QUEUE_PROFILE
+        cnt[6] += __builtin_amdgcn_s_memtime() - sp0_;
+#endif
         pending = 0;
       }
       if (need) gathered[pending + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint16_t)i;
@@ -744,10 +785,23 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       for (int k = 0; k < 2; ++k) { lo[k] = wave_min_dpp_last(lo[k]); hi[k] = wave_max_dpp_last(hi[k]); }
     }
     if (lane == 63) {
-      double* row = rows + (size_t)r * RS;
+      if (QEXP_PAIR == 1 || nslabs <= QEXP_MOM) {
+        double* row = rows + (size_t)r * RS;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) row[k] = a[k];
-      if (box) { row[9] = lo[0]; row[10] = lo[1]; row[11] = hi[0]; row[12] = hi[1]; }
+        for (int k = 0; k < 9; ++k) row[k] = a[k];
+        if (box) { row[9] = lo[0]; row[10] = lo[1]; row[11] = hi[0]; row[12] = hi[1]; }
+      } else {
+        typedef __attribute__((address_space(3))) double* LdsDouble;
+        LdsDouble row = (LdsDouble)(rows + (size_t)(r / QEXP_PAIR) * RS);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) (void)__hip_atomic_fetch_add(row + k, a[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (box) {
+          (void)__hip_atomic_fetch_min(row + 9, lo[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          (void)__hip_atomic_fetch_min(row + 10, lo[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          (void)__hip_atomic_fetch_max(row + 11, hi[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          (void)__hip_atomic_fetch_max(row + 12, hi[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
     }
     QUEUE_MARK(1);
   };
@@ -774,7 +828,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
       if (phase != 0) break;
-      const int nrows = moment_tasks(lds_load_i32(&c->nslabs));
+      const int nrows = moment_tasks(lds_load_i32(&c->nslabs));      // tasks of the moment round
       if (nrows > 1) {                                         // a large problem: its moments are a round of tasks as well
         if (lane == 0) { c->phase = 1; c->done_tasks = 0; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -805,6 +859,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       const unsigned t = old & 0xffffu, ntasks = old >> 16;
       if (t < ntasks) {
         QUEUE_MARK(4);
+        QUEUE_COUNT(7, 1);
         run_task(q, (int)t, (int)ntasks);
         pref = q;
         idle_since = -1;
@@ -830,7 +885,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   // cycles per phase and search statistics summed over the waves of the launch (printed by the launcher under LSLAM_DEBUG)
   if (lay.debug && lane == 0) {
     for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(lay.queue + 4) + k, prof[k]);
-    for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(lay.queue + 4) + 6 + k, cnt[k]);
+    for (int k = 0; k < 8; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(lay.queue + 4) + 6 + k, cnt[k]);
   }
 #endif
 }
@@ -876,7 +931,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
     lay.src_off = 0xffffffffu;
     if (src_in_lds) { lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * (f64 ? sizeof(double2) : sizeof(float2))); }
     lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));
-    lay.margin_off = (uint32_t)off; if (certify) off += up((size_t)max_src_n * sizeof(uint16_t));
+    lay.margin_off = (uint32_t)off; if (certify && !f64) off += up((size_t)max_src_n * sizeof(uint16_t));      // float64-exact mode: sc.margins
     lay.rows_off = (uint32_t)off; off += sizeof(double) * (size_t)(rows_cap * RS > 16 ? rows_cap * RS : 16);
     return up(off);
   };
@@ -907,9 +962,9 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   // one slot per CU (a 4096-point problem in float64-exact mode): its rounds of 8–16 tasks do not feed 16 waves, and the idle ones poll
   // the LDS the working ones read (C4 float64-exact: 11.9 against 12.6 ms)
   if (Q == 1 && certify && W > 8 && !getenv("LSLAM_ICP_QUEUE_WAVES")) W = 8;
-  // one slot per CU: a second round of tasks per iteration only adds hand-offs (C4 float64-exact 11.4 -> 10.7 ms); with three slots the
-  // fused tasks are too few and too coarse (5.7 -> 5.8 ms)
-  lay.fuse = env_int("LSLAM_ICP_QUEUE_FUSE", Q == 1 ? 1 : 0);
+  // fused tasks from the second iteration on: a second round of tasks per iteration only adds hand-offs (C4, three slots of eight tasks:
+  // 5.60 -> 5.23 ms; float64-exact, two slots: 9.5 -> 9.0 ms)
+  lay.fuse = env_int("LSLAM_ICP_QUEUE_FUSE", 1);
   lay.slot_bytes = (uint32_t)slot;
   lay.ctl_bytes = (uint32_t)up((size_t)Q * kQCtlBytes + 64 + 128 + (size_t)kIcpBatchMaxWaves * kWave * sizeof(uint16_t));
   lay.Q = Q;
@@ -919,6 +974,9 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   lay.ecap_frac = 0.25f;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_ECAP")) lay.ecap_frac = (float)atof(e);
   lay.queue = sc.queue;
+  lay.margins = sc.margins;
+  lay.margin_stride = (uint32_t)((max_src_n + 63) & ~(int64_t)63);
+  if (f64 && certify && (!sc.margins || (size_t)(S < cus ? S : cus) * 16 * lay.margin_stride > sc.margin_cap)) return hipErrorInvalidValue;
   lay.debug = getenv("LSLAM_DEBUG") ? 1 : 0;
   const size_t smem = lay.ctl_bytes + (size_t)Q * slot;
   if (smem > kLdsPerCu) return hipErrorInvalidValue;
@@ -926,22 +984,24 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   if (grid > cus) grid = cus;
   const int threads = W * 64;
   if (lay.debug) {
-    unsigned long long h[16];
+    unsigned long long h[18];
     (void)hipStreamSynchronize(stream);
-    (void)hipMemcpy(h, sc.queue, 128, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h, sc.queue, 144, hipMemcpyDeviceToHost);
     const unsigned* hu = reinterpret_cast<const unsigned*>(h);
     fprintf(stderr, "[lslam] queue kernel, previous launch: problems drawn %u, timeouts %u, tie passes %u\n", hu[0], hu[1], hu[2]);
 #ifdef LSLAM_QUEUE_PROFILE
     double tot = 0; for (int k = 0; k < 6; ++k) tot += (double)h[2 + k];
     if (tot > 0) fprintf(stderr, "[lslam] queue kernel, share of wave cycles: search %.3f  moments %.3f  reduce+solve %.3f  outputs+staging %.3f  idle %.3f  idle while draining %.3f\n",
                          h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot, h[7] / tot);
+    if (h[8] > 0) fprintf(stderr, "[lslam] queue kernel, gathered searches: %.3f of the search cycles (%.0f ticks each); %.0f ticks of search+moment+solve per task, %llu tasks\n",
+                          (double)h[14] / (double)(h[2] ? h[2] : 1), (double)h[14] / h[8], (double)(h[2] + h[3] + h[4]) / (double)(h[15] ? h[15] : 1), h[15]);
     if (h[8] > 0) fprintf(stderr, "[lslam] queue kernel, per search of <= 64 sources: %.2f surviving boxes, %.2f list rounds, %.2f (point, chunk) entries; %.3f of the sources visited were searched (%.1f per search)\n",
                           (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[13] / (double)(h[12] ? h[12] : 1), (double)h[13] / h[8]);
 #endif
     fprintf(stderr, "[lslam] icp_queue_kernel: %d workgroups x %d waves, %d slots of %zu B (%zu B LDS), %d rows per slot, %s\n",
             grid, W, Q, slot, smem, rows_cap, f64 ? "float64-exact" : "float32");
   }
-  hipError_t e = hipMemsetAsync(sc.queue, 0, 128, stream);
+  hipError_t e = hipMemsetAsync(sc.queue, 0, 144, stream);
   if (e != hipSuccess) return e;
   auto launch = [&](auto kernel) -> hipError_t {
     hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

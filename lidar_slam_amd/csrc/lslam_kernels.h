@@ -75,6 +75,7 @@ struct PruneScratch {                      // Morton-sorted copies: problem k ow
   // float64-exact mode: the float64 clouds in the same sorted order (written by icp_sort_kernel), so that the moments read
   // them sequentially / from neighbouring lines instead of gathering 16 bytes per point from the caller's order
   double2* src64_sorted; double2* tgt64_sorted;
+  uint16_t* margins; size_t margin_cap;    // float64-exact mode, task-queue kernel: a row of margins (halves) per LDS slot of every workgroup; capacity in entries
   unsigned* queue;                         // 256 bytes: [0] next problem of the task-queue kernel, [1] waves that gave up waiting, [2] tie passes, [4…] profile
 };
 // lslam_icp_queue.hip: byte offsets inside one LDS slot (the target tile is at 0), slots per workgroup, slabs per task
@@ -87,6 +88,7 @@ struct QueueLayout {
   int32_t Q, G, rows_cap;                                          // G = 0: task size chosen per problem and iteration
   unsigned* queue;
   int32_t debug;
+  uint16_t* margins; uint32_t margin_stride;                       // float64-exact mode: slot q of workgroup b keeps its margins at margins[(b·Q + q)·margin_stride …]
 };
 hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n, hipStream_t stream);
 struct PruneLayout { uint32_t aabb_off, src_off, prev_off, red_off; unsigned* debug_counter; uint32_t slab_off; };   // slab_off: planar kernel only
