@@ -192,8 +192,8 @@ struct PruneHolder {
       LSLAM_HIP_TRY(hipMalloc(&sc.tgt64_sorted, sizeof(double2) * need_tgt));
       cap_src64 = need_src; cap_tgt64 = need_tgt;
     }
-    // … and the task-queue kernel's margins: at most 16 slots of kPruneMaxPoints sources per workgroup, one workgroup per CU
-    if (f64 && !sc.margins) {
+    // the task-queue kernel's margins (float64-exact mode, running sums): at most 16 slots of kPruneMaxPoints sources per workgroup, one workgroup per CU
+    if (!sc.margins) {
       int cus = 0;
       LSLAM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
       if (cus <= 0) cus = 256;

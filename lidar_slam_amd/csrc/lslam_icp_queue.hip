@@ -80,6 +80,7 @@ struct QueueCtl {                                      // one per slot, in LDS; 
   float stepR, stepT;                                  // ‖R_k − R_{k−1}‖_F and |t_k − t_{k−1}| of the transform the current iteration searches with (rounded up)
   float extend;                                        // E of the current iteration's searches
   float ecap;                                          // cap of E for this problem
+  uint32_t dirty;                                      // running-sums build: bit t = task t of this round left a row of changes
 };
 static_assert(sizeof(QueueCtl) <= kQCtlBytes, "control block");
 #define QCTL_DWORD(field) (int)(offsetof(QueueCtl, field) / 4)
@@ -103,6 +104,35 @@ __device__ __forceinline__ int ctl_load(const QueueCtl* c, int lane) {
 #define CTL_INT(cw, field) __builtin_amdgcn_readlane(cw, QCTL_DWORD(field))
 #define CTL_FLOAT(cw, field) __int_as_float(__builtin_amdgcn_readlane(cw, QCTL_DWORD(field)))
 #define CTL_T(cw, k) __hiloint2double(__builtin_amdgcn_readlane(cw, 2 * (k) + 1), __builtin_amdgcn_readlane(cw, 2 * (k)))
+
+// ---- double-double sums (the running-sums build, below): value = hi + lo, |lo| tiny; every product enters exactly (two_prod), every
+// addition keeps its rounding error (two_sum) — the pair is good to ~1e-32 of the largest magnitude met, and is not kept normalised
+struct DD { double hi, lo; };
+__device__ __forceinline__ void two_sum(double a, double b, double& s, double& e) { s = a + b; const double bb = s - a; e = (a - (s - bb)) + (b - bb); }
+__device__ __forceinline__ void two_prod(double a, double b, double& p, double& e) { p = a * b; e = __builtin_fma(a, b, -p); }
+__device__ __forceinline__ void dd_acc(DD& a, double x) { double s, e; two_sum(a.hi, x, s, e); a.hi = s; a.lo += e; }
+__device__ __forceinline__ void dd_acc_prod(DD& a, double x, double y) { double p, pe, s, e; two_prod(x, y, p, pe); two_sum(a.hi, p, s, e); a.hi = s; a.lo += e + pe; }
+__device__ __forceinline__ void dd_add(DD& a, const DD& b) { double s, e; two_sum(a.hi, b.hi, s, e); a.hi = s; a.lo += e + b.lo; }
+__device__ __forceinline__ DD dd_prod_diff(double a, double bn, double bo) {      // a·bn − a·bo
+  double pn, en, po, eo; two_prod(a, bn, pn, en); two_prod(a, bo, po, eo);
+  DD r; two_sum(pn, -po, r.hi, r.lo); r.lo += en - eo; return r;
+}
+__device__ __forceinline__ DD dd_sq_diff(double a, double b) {      // a² − b²
+  double pn, en, po, eo; two_prod(a, a, pn, en); two_prod(b, b, po, eo);
+  DD r; two_sum(pn, -po, r.hi, r.lo); r.lo += en - eo; return r;
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ void dd_dpp_step(DD& v) { const DD o{dpp_d<CTRL, ROWS>(v.hi), dpp_d<CTRL, ROWS>(v.lo)}; dd_add(v, o); }
+__device__ __forceinline__ DD wave_sum_dd_last(DD v) {          // the sum over the wave, valid in lane 63 only (the order of wave_sum_dpp_last)
+  dd_dpp_step<kDppXor1, 0xf>(v); dd_dpp_step<kDppXor2, 0xf>(v); dd_dpp_step<kDppHalfMirror, 0xf>(v);
+  dd_dpp_step<kDppMirror, 0xf>(v); dd_dpp_step<kDppBcast15, 0xa>(v); dd_dpp_step<kDppBcast31, 0xc>(v);
+  return v;
+}
+constexpr int kQBase = 12;                             // running sums (DD each): Σx Σy Σxx Σxy Σyy of the sources | Σqx Σqy | Σx·qx Σx·qy Σy·qx Σy·qy | Σ|q|² of the matches
+constexpr int kQDelta = 7;                             // … of which the last seven depend on the matches
+constexpr int kQDeltaRows = 16;                        // tasks of a round that may leave a row of changes
+constexpr int kQBaseRows = 8;                          // tasks of the first iteration's round of sums
+constexpr int kQIncrDoubles = 2 * kQBase + (2 * kQDelta * kQDeltaRows > 2 * kQBase * kQBaseRows ? 2 * kQDelta * kQDeltaRows : 2 * kQBase * kQBaseRows);
 
 // A float32 source from its LDS copy or, where a slot has no room for one, from the sorted copy in memory — as two explicit
 // paths: written as one conditional expression the compiler selects between the two POINTERS and emits a flat_load (the slow
@@ -183,7 +213,8 @@ __device__ __forceinline__ void queue_eval_chunk(unsigned tile0, int chunk, floa
 #endif
 
 // CERT: sources keep their match on a proof (margins; see the header) instead of being searched in every iteration
-template <bool F64, bool CERT>
+// INCR (needs CERT, no normalised error): running sums instead of a pass over all pairs per iteration — see `finish`
+template <bool F64, bool CERT, bool INCR>
 __global__ void __launch_bounds__(kIcpBatchMaxThreads, 4)      // ≤ 128 VGPRs: one workgroup of up to 16 waves per CU (the VALU is saturated by four waves per SIMD: tools/queue_stats.sh)
 icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   constexpr int CHUNK = kPruneChunk;
@@ -246,15 +277,19 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   auto moment_rows = [&](int nslabs) -> int { return nslabs <= QEXP_MOM ? 1 : (moment_tasks(nslabs) + QEXP_PAIR - 1) / QEXP_PAIR; };
   // rows that tasks ADD into start from the neutral element (one wave; the caller publishes the stores with its release fence)
   auto clear_rows = [&](unsigned char* base, int nslabs) {
-    if (QEXP_PAIR == 1 || nslabs <= QEXP_MOM) return;
+    if (INCR || QEXP_PAIR == 1 || nslabs <= QEXP_MOM) return;
     double* rows = reinterpret_cast<double*>(base + lay.rows_off);
     for (int k = lane; k < moment_rows(nslabs) * RS; k += kWave) { const int cl = k % RS; rows[k] = cl < 9 ? 0.0 : (cl < 11 ? (double)INFINITY : -(double)INFINITY); }
   };
 
+  // running-sums build: the first iteration's round of sums — tasks of 8 slabs (16 above 64 slabs), one row of kQBase DD sums each
+  auto base_slabs = [&](int nslabs) -> int { return nslabs <= 8 * kQBaseRows ? 8 : 16; };
+  auto base_tasks = [&](int nslabs) -> int { return nslabs > 0 ? (nslabs + base_slabs(nslabs) - 1) / base_slabs(nslabs) : 1; };
+
   // margins: in LDS; in float64-exact mode (whose slot also holds the targets' float64 residuals) in this workgroup's rows of a scratch
   // buffer in memory, read and written a slab at a time — the workgroup's waves share the CU's L1, workgroup-scope fences order them
   auto margins_of = [&](int q, unsigned char* base) -> uint16_t* {
-    if constexpr (F64) return lay.margins + ((size_t)blockIdx.x * (size_t)Q + (size_t)q) * lay.margin_stride;
+    if constexpr (F64 || INCR) return lay.margins + ((size_t)blockIdx.x * (size_t)Q + (size_t)q) * lay.margin_stride;
     else return reinterpret_cast<uint16_t*>(base + lay.margin_off);
   };
 
@@ -288,7 +323,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         tmax = fmaxf(tmax, __builtin_fmaf(v.y, v.y, v.x * v.x));
         if constexpr (CERT) { bx0 = fminf(bx0, v.x); by0 = fminf(by0, v.y); bx1 = fmaxf(bx1, v.x); by1 = fmaxf(by1, v.y); }
       }
-      if constexpr (F64) {
+      if constexpr (F64 && !INCR) {
         int2 d = make_int2(0, 0);
         if (j < m) {
           const double2 td = sc.tgt64_sorted[ts + j];
@@ -298,7 +333,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       }
     }
     // sources (all loads in flight before the first use), no matches and no margins yet
-    for (int i0 = 0; i0 < n; i0 += 8 * kWave) {
+    for (int i0 = 0; src_lds && i0 < n; i0 += 8 * kWave) {
       if constexpr (F64) {
         double2 pd[8];
 #pragma unroll
@@ -348,7 +383,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       c->stop = st0; c->err = 0.0;
       c->problem = p; c->n = n; c->m = m; c->nchunks = nchunks; c->nslabs = nslabs;
       c->G = G; c->phase = 0;
-      c->done_tasks = 0;
+      c->done_tasks = 0; c->dirty = 0u;
       c->Rt = sqrtf(tmax) * 1.0001f;
       c->Rs = sqrtf(smax) * 1.0001f;
       c->stepR = INFINITY; c->stepT = INFINITY;               // no earlier transform: nothing is certified in the first iteration
@@ -367,6 +402,79 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     unsigned char* base = slot_of(q);
     double* rows = reinterpret_cast<double*>(base + lay.rows_off);       // [queue_rows][RS]
     const int n = lds_load_i32(&c->n), nslabs = lds_load_i32(&c->nslabs);
+    Moments mo;
+    mo.n = (double)n;                                          // every source has a match: the count is the cloud's size
+    for (int i = 0; i < 3; ++i) { mo.sp[i] = 0.0; mo.sq[i] = 0.0; mo.lo[i] = 0.0; mo.hi[i] = 0.0; }
+    for (int i = 0; i < 9; ++i) mo.spq[i] = 0.0;
+    double* scratch = rows;                                    // 16 doubles the solve may use once the rows are consumed
+    if constexpr (INCR) {
+      // ---- running sums.  The transform enters the moments of the matched pairs only through products with sums that do not
+      // depend on it: with u_i = (T_i0, T_i1, T_i3), P = Σ (x, y, 1)(x, y, 1)ᵀ over the ORIGINAL sources and c_i = (Σ x·q_i, Σ y·q_i, Σ q_i),
+      //   Σ (Tp)_i = u_i·P_2,   Σ (Tp)_i q_j = u_i·c_j,   Σ ‖Tp − q‖² = Σ|q|² + Σ_i (u_iᵀ P u_i − 2 u_i·c_i).
+      // P is fixed, c and Σ|q|² change only where a match changes: the first iteration sums them over all pairs (base_task), later
+      // ones add the changes their searches found (search_points).  The last formula cancels (terms ~ n·r², result ~ n·residual²), so
+      // the sums are kept as double-doubles and the 25 products are formed exactly: the error is that of the exact sum for this T —
+      // closer to it than a per-pair pass in float64 — and the per-iteration pass over all pairs is gone.
+      double* sums = rows;                                     // [kQBase] DD
+      double* drow = rows + 2 * kQBase;                        // the rows the round's tasks left
+      scratch = drow;
+      const bool full = !(__int_as_float(lds_load_i32(reinterpret_cast<const int32_t*>(&c->stepR))) < INFINITY);
+      const int k = lane < kQBase ? lane : 0;
+      DD v;
+      if (full) {
+        const int nt = base_tasks(nslabs);
+        v = DD{drow[2 * k], drow[2 * k + 1]};
+        for (int r = 1; r < nt; ++r) dd_add(v, DD{drow[(size_t)r * 2 * kQBase + 2 * k], drow[(size_t)r * 2 * kQBase + 2 * k + 1]});
+      } else {
+        v = DD{sums[2 * k], sums[2 * k + 1]};
+        unsigned dirty = lds_load_u32(&c->dirty);
+        const int kd = k - (kQBase - kQDelta);
+        while (dirty) {                                        // task order: which wave ran which task does not matter
+          const int t = __builtin_ctz(dirty);
+          dirty &= dirty - 1u;
+          if (kd >= 0) dd_add(v, DD{drow[(size_t)t * 2 * kQDelta + 2 * kd], drow[(size_t)t * 2 * kQDelta + 2 * kd + 1]});
+        }
+      }
+      { double s_, e_; two_sum(v.hi, v.lo, s_, e_); v.hi = s_; v.lo = e_; }      // hi = the sum rounded to a double
+      if (lane < kQBase) { sums[2 * lane] = v.hi; sums[2 * lane + 1] = v.lo; }
+      double B[kQBase];
+#pragma unroll
+      for (int kk = 0; kk < kQBase; ++kk)
+        B[kk] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.hi), kk), __builtin_amdgcn_readlane(__double2loint(v.hi), kk));
+      const double T00 = c->T[0], T01 = c->T[1], T03 = c->T[3], T10 = c->T[4], T11 = c->T[5], T13 = c->T[7];
+      mo.sp[0] = T00 * B[0] + T01 * B[1] + T03 * mo.n; mo.sp[1] = T10 * B[0] + T11 * B[1] + T13 * mo.n;
+      mo.sq[0] = B[5]; mo.sq[1] = B[6];
+      mo.spq[0] = T00 * B[7] + T01 * B[9] + T03 * B[5]; mo.spq[1] = T00 * B[8] + T01 * B[10] + T03 * B[6];
+      mo.spq[3] = T10 * B[7] + T11 * B[9] + T13 * B[5]; mo.spq[4] = T10 * B[8] + T11 * B[10] + T13 * B[6];
+      // Σ‖Tp − q‖²: lane L < 24 forms one product of row i = L / 12 (nine u_a·u_b·P_ab, three −2·u_a·c_a), lane 24 brings Σ|q|²
+      DD term{0.0, 0.0};
+#ifdef QX_NOTERM
+      if (false) {
+#else
+      if (lane < 25) {
+#endif
+        const int i = lane >= 12 ? 1 : 0, r = lane - 12 * i;
+        const int a = r < 9 ? r / 3 : r - 9, b = r < 9 ? r - 3 * (r / 3) : 0;
+        constexpr unsigned long long kPIdx = 2ull | 3ull << 4 | 0ull << 8 | 3ull << 12 | 4ull << 16 | 1ull << 20 | 0ull << 24 | 1ull << 28 | 15ull << 32;
+        int idx = r < 9 ? (int)((kPIdx >> (4 * (3 * a + b))) & 15ull) : (a == 0 ? 7 + i : (a == 1 ? 9 + i : 5 + i));
+        double f1 = c->T[4 * i + (a < 2 ? a : 3)];
+        double f2 = r < 9 ? c->T[4 * i + (b < 2 ? b : 3)] : -2.0;
+        if (lane == 24) { idx = 11; f1 = 1.0; f2 = 1.0; }
+        const DD D = idx == 15 ? DD{mo.n, 0.0} : DD{sums[2 * idx], sums[2 * idx + 1]};
+        double ph, pl, h, l;
+        two_prod(f1, f2, ph, pl);
+        two_prod(ph, D.hi, h, l);
+        l += ph * D.lo + pl * D.hi;
+        term = DD{h, l};
+      }
+      term = wave_sum_dd_last(term);
+      const double sse_l = term.hi + term.lo;
+      const double sse = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sse_l), 63), __builtin_amdgcn_readlane(__double2loint(sse_l), 63));
+      mo.sse = sse < 0.0 ? 0.0 : sse;
+      if (n == 1) {                                            // one pair: the centred cross-covariance is zero by definition, not to rounding (S = spq − sp·sqᵀ/n)
+        mo.spq[0] = mo.sp[0] * mo.sq[0]; mo.spq[1] = mo.sp[0] * mo.sq[1]; mo.spq[3] = mo.sp[1] * mo.sq[0]; mo.spq[4] = mo.sp[1] * mo.sq[1];
+      }
+    } else {
     const int ntasks = moment_rows(nslabs);                    // rows of partial sums
     double col;
     {
@@ -392,18 +500,15 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       const int hi = __builtin_amdgcn_readlane(__double2hiint(col), k);
       tot[k] = __hiloint2double(hi, lo);
     }
-    Moments mo;
-    mo.n = (double)n;                                          // every source has a match: the count is the cloud's size
-    for (int i = 0; i < 3; ++i) { mo.sp[i] = 0.0; mo.sq[i] = 0.0; mo.lo[i] = 0.0; mo.hi[i] = 0.0; }
-    for (int i = 0; i < 9; ++i) mo.spq[i] = 0.0;
     mo.sp[0] = tot[0]; mo.sp[1] = tot[1]; mo.sq[0] = tot[2]; mo.sq[1] = tot[3];
     mo.spq[0] = tot[4]; mo.spq[1] = tot[5]; mo.spq[3] = tot[6]; mo.spq[4] = tot[7];
     mo.sse = tot[8];
     if (box) { mo.lo[0] = tot[9]; mo.lo[1] = tot[10]; mo.hi[0] = tot[11]; mo.hi[1] = tot[12]; }
+    }
     double R[9], pb[3], qb[3];
     step_parts(mo, true, R, pb, qb);
     const double told = c->T[lane & 15];
-    const double tn = step_times_prev_lane(R, pb, qb, c->T, rows, lane);   // element `lane` of T_step·T_prev (the rows are consumed: their first 16 doubles serve as its scratch)
+    const double tn = step_times_prev_lane(R, pb, qb, c->T, scratch, lane);   // element `lane` of T_step·T_prev (the rows are consumed: their first 16 doubles serve as its scratch)
     // how far the new transform can move a source p: ‖ΔR‖₂·|p| + |Δt|, rounded up
     float stepR = INFINITY, stepT = INFINITY;
     if constexpr (CERT) {
@@ -422,11 +527,16 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     QUEUE_MARK(2);
     if (!stop) {
       // from the second iteration on, with certificates: one round of fused tasks (a moment group's slabs searched, then its row)
-      const bool fuse = CERT && lay.fuse && moment_tasks(nslabs) > 1;
-      const int G = fuse ? moment_slabs(nslabs) : search_group(nslabs, st.executed);
+      const bool fuse = CERT && !INCR && lay.fuse && moment_tasks(nslabs) > 1;
+      int G = fuse ? moment_slabs(nslabs) : search_group(nslabs, st.executed);
+      if constexpr (INCR) {
+        // a task may leave a row of changes: at most kQDeltaRows tasks, and a grouping that depends on the problem's size alone
+        G = lay.G > 0 ? lay.G : (nslabs > 32 ? 8 : 4);
+        if (G * kQDeltaRows < nslabs) G = (nslabs + kQDeltaRows - 1) / kQDeltaRows;
+      }
       clear_rows(base, nslabs);
       if (lane == 0) {
-        c->stop = st; c->err = err; c->done_tasks = 0;
+        c->stop = st; c->err = err; c->done_tasks = 0; c->dirty = 0u;
         c->G = G; c->phase = fuse ? 2 : 0;
         c->stepR = stepR; c->stepT = stepT;
         // the next searches extend their reach by E ≈ kQExtend × this step (the steps of a converging run shrink geometrically:
@@ -490,6 +600,12 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     auto target_at = [&](int j) { return *reinterpret_cast<const float2*>(base + rec_off(j)); };
     auto box_at = [&](int cidx) { return *reinterpret_cast<const float4*>(base + (size_t)cidx * kQRec + CHUNK * 8); };
 
+    // running-sums build: after the first iteration (whose sums base_task takes over all pairs) a search adds what its changed matches
+    // change to row t of the round; task_dirty: the row has been written
+    const bool changes_wanted = INCR && stepR < INFINITY;
+    bool task_dirty = false;
+    double* drow = reinterpret_cast<double*>(base + lay.rows_off) + 2 * kQBase + (size_t)t * 2 * kQDelta;
+
     // ---- the nearest neighbours of up to 64 sources, one per lane (i: the lane's source, owns: it has one): exact search, then
     // the source's margin for the iterations to come
     auto search_points = [&](int i, bool owns) {
@@ -509,10 +625,10 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       // target by target by the lane itself: an exact bound before any box test
       float bd = owns ? INFINITY : -INFINITY;                  // lanes without a point never ask for a chunk
       float sec = INFINITY;
-      int pos = 0, own = -1;
+      int pos = 0, own = -1, pv = 0xffff;
       bool tie = false;
       if (owns) {
-        const int pv = sh_prev[i];
+        pv = sh_prev[i];
         own = (pv != 0xffff ? pv : (int)(((long long)i * m) / n)) / CHUNK;
         queue_eval_chunk<F64 || CERT>(tile0, own, ax, ay, bd, sec, pos);
       }
@@ -644,6 +760,39 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
           }
         }
       }
+      if constexpr (INCR) {
+        const bool changed = changes_wanted && owns && pos != pv && pv != 0xffff;
+#ifdef QX_NODELTA
+        if (false) {
+#else
+        if (__any(changed)) {
+#endif
+          double x = 0.0, y = 0.0, qnx = 0.0, qny = 0.0, qox = 0.0, qoy = 0.0;
+          if (changed) {
+            if constexpr (F64) {
+              const double2 sp = gsrc64[i], tn_ = gtgt64[pos], to_ = gtgt64[pv];
+              x = sp.x; y = sp.y; qnx = tn_.x; qny = tn_.y; qox = to_.x; qoy = to_.y;
+            } else {
+              const float2 v = gsrc[i], tn_ = target_at(pos), to_ = target_at(pv);
+              x = (double)v.x; y = (double)v.y; qnx = (double)tn_.x; qny = (double)tn_.y; qox = (double)to_.x; qoy = (double)to_.y;
+            }
+          }
+          auto leave = [&](int k, DD d) {                      // the wave's change of sum k, added to the task's row by lane 63
+            d = wave_sum_dd_last(d);
+            if (lane == 63) {
+              if (task_dirty) dd_add(d, DD{drow[2 * k], drow[2 * k + 1]});
+              drow[2 * k] = d.hi; drow[2 * k + 1] = d.lo;
+            }
+            __builtin_amdgcn_sched_barrier(0);                 // one sum at a time: seven in flight spill
+          };
+          { DD d; two_sum(qnx, -qox, d.hi, d.lo); leave(0, d); }
+          { DD d; two_sum(qny, -qoy, d.hi, d.lo); leave(1, d); }
+          leave(2, dd_prod_diff(x, qnx, qox)); leave(3, dd_prod_diff(x, qny, qoy));
+          leave(4, dd_prod_diff(y, qnx, qox)); leave(5, dd_prod_diff(y, qny, qoy));
+          { DD d = dd_sq_diff(qnx, qox), e = dd_sq_diff(qny, qoy); dd_add(d, e); leave(6, d); }
+          task_dirty = true;
+        }
+      }
       if (owns) {
         sh_prev[i] = (uint16_t)pos;
         // The margin.  Real distances: nearest d1 ≤ √bd·(1+3u); every other target is at least L = min(√sec, √bd_seed + E)·(1−3u)
@@ -724,11 +873,84 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       if (need) gathered[pending + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint16_t)i;
       pending += nneed;
     }
+    if constexpr (INCR) {
+      if (task_dirty && lane == 0) atomicOr(&c->dirty, 1u << t);
+    }
     QUEUE_MARK(0);
+  };
+
+  // ---- one wave (running-sums build, first iteration): row r of the sums over all pairs, as double-doubles ----------------------
+  auto base_task = [&](int q, int r) {
+#ifdef QX_NOBASE
+    if constexpr (false) {
+#else
+    if constexpr (INCR) {
+#endif
+      QueueCtl* c = ctl_of(q);
+      unsigned char* base = slot_of(q);
+      const uint16_t* sh_prev = reinterpret_cast<const uint16_t*>(base + lay.prev_off);
+      double* drow = reinterpret_cast<double*>(base + lay.rows_off) + 2 * kQBase + (size_t)r * 2 * kQBase;
+      const int cw = ctl_load(c, lane);
+      const int n = CTL_INT(cw, n), nslabs = CTL_INT(cw, nslabs), p = CTL_INT(cw, problem);
+      const float2* __restrict__ gsrc = sc.src_sorted + (int64_t)p * sc.src_stride;
+      const double2* __restrict__ gsrc64 = F64 ? sc.src64_sorted + (int64_t)p * sc.src_stride : nullptr;
+      const double2* __restrict__ gtgt64 = F64 ? sc.tgt64_sorted + (int64_t)p * sc.tgt_stride : nullptr;
+      const int slab_lo = r * base_slabs(nslabs), slab_hi = min(slab_lo + base_slabs(nslabs), nslabs);
+      // three passes of at most five sums each (twelve double-double accumulators at once do not fit the 128 registers of a 16-wave workgroup)
+      auto source_at = [&](int i, double& x, double& y) {
+        if constexpr (F64) { const double2 sp = gsrc64[i]; x = sp.x; y = sp.y; }
+        else { const float2 v = gsrc[i]; x = (double)v.x; y = (double)v.y; }
+      };
+      auto match_at = [&](int i, double& qx, double& qy) {
+        const int ps = sh_prev[i];
+        if constexpr (F64) { const double2 tq = gtgt64[ps]; qx = tq.x; qy = tq.y; }
+        else { const float2 qv = *reinterpret_cast<const float2*>(base + rec_off(ps)); qx = (double)qv.x; qy = (double)qv.y; }
+      };
+      auto leave = [&](int k0, DD v) {                       // sum k0 of the row, from lane 63
+        v = wave_sum_dd_last(v);
+        if (lane == 63) { drow[2 * k0] = v.hi; drow[2 * k0 + 1] = v.lo; }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      {
+        DD a0{0.0, 0.0}, a1{0.0, 0.0}, a2{0.0, 0.0}, a3{0.0, 0.0}, a4{0.0, 0.0};
+        for (int slab = slab_lo; slab < slab_hi; ++slab) {
+          const int i = slab * kWave + lane;
+          if (i < n) {
+            double x, y; source_at(i, x, y);
+            dd_acc(a0, x); dd_acc(a1, y); dd_acc_prod(a2, x, x); dd_acc_prod(a3, x, y); dd_acc_prod(a4, y, y);
+          }
+        }
+        leave(0, a0); leave(1, a1); leave(2, a2); leave(3, a3); leave(4, a4);
+      }
+      {
+        DD a5{0.0, 0.0}, a6{0.0, 0.0}, a11{0.0, 0.0};
+        for (int slab = slab_lo; slab < slab_hi; ++slab) {
+          const int i = slab * kWave + lane;
+          if (i < n) {
+            double qx, qy; match_at(i, qx, qy);
+            dd_acc(a5, qx); dd_acc(a6, qy); dd_acc_prod(a11, qx, qx); dd_acc_prod(a11, qy, qy);
+          }
+        }
+        leave(5, a5); leave(6, a6); leave(11, a11);
+      }
+      {
+        DD a7{0.0, 0.0}, a8{0.0, 0.0}, a9{0.0, 0.0}, a10{0.0, 0.0};
+        for (int slab = slab_lo; slab < slab_hi; ++slab) {
+          const int i = slab * kWave + lane;
+          if (i < n) {
+            double x, y, qx, qy; source_at(i, x, y); match_at(i, qx, qy);
+            dd_acc_prod(a7, x, qx); dd_acc_prod(a8, x, qy); dd_acc_prod(a9, y, qx); dd_acc_prod(a10, y, qy);
+          }
+        }
+        leave(7, a7); leave(8, a8); leave(9, a9); leave(10, a10);
+      }
+      QUEUE_MARK(1);
+    }
   };
 
   // ---- one wave: row r of the slot's float64 partial sums — the matched pairs of slabs [r·moment_slabs(), …) --------------------
   auto moment_task = [&](int q, int r) {
+    if constexpr (INCR) return;
     QueueCtl* c = ctl_of(q);
     unsigned char* base = slot_of(q);
     const int2* tdelta = reinterpret_cast<const int2*>(base + lay.tdelta_off);
@@ -817,7 +1039,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     bool solo = false;                                         // the one moment task of a small problem, run by the wave that closed its search round
     for (;;) {                                                 // (a loop so that each routine has one call site)
       if (phase != 1) search_task(q, t);
-      if (phase != 0) moment_task(q, t);
+      if (phase != 0) { if constexpr (INCR) base_task(q, t); else moment_task(q, t); }
       if (!solo) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         unsigned d = 0;
@@ -828,7 +1050,10 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
       if (phase != 0) break;
-      const int nrows = moment_tasks(lds_load_i32(&c->nslabs));      // tasks of the moment round
+      if constexpr (INCR) {                                    // after the first iteration the searches have left their changes: no second round
+        if (__int_as_float(lds_load_i32(reinterpret_cast<const int32_t*>(&c->stepR))) < INFINITY) break;
+      }
+      const int nrows = INCR ? base_tasks(lds_load_i32(&c->nslabs)) : moment_tasks(lds_load_i32(&c->nslabs));      // tasks of the moment round
       if (nrows > 1) {                                         // a large problem: its moments are a round of tasks as well
         if (lane == 0) { c->phase = 1; c->done_tasks = 0; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -921,18 +1146,20 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   // slabs, and the margins cost a slot of LDS (C3: 0.72 -> 0.85 ms): from 2048 points per cloud by default.
   bool certify = max_src_n >= 2048 || max_tgt_n >= 2048;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_CERTIFY")) certify = atoi(e) != 0;
+  // running sums instead of a pass over all pairs per iteration (see finish): with certificates, unless the normalised error's box is asked for
+  const bool incr = certify && !box && env_int("LSLAM_ICP_QUEUE_INCR", 1) != 0;
   const int rows_cap = queue_rows(f64);
   lay.rows_cap = rows_cap;
   // a slot's layout; float32 sources live in LDS when two slots still fit a CU, else they are read from the sorted copy in memory
   // (once per search and once per moment task, coalesced: 4096-point problems then keep two slots per CU)
   auto layout = [&](bool src_in_lds) -> size_t {
     size_t off = (size_t)nchunks * kQRec;
-    lay.tdelta_off = (uint32_t)off; if (f64) off += (size_t)padded * sizeof(float2);
+    lay.tdelta_off = (uint32_t)off; if (f64 && !incr) off += (size_t)padded * sizeof(float2);
     lay.src_off = 0xffffffffu;
-    if (src_in_lds) { lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * (f64 ? sizeof(double2) : sizeof(float2))); }
+    if (src_in_lds && !incr) { lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * (f64 ? sizeof(double2) : sizeof(float2))); }
     lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));
-    lay.margin_off = (uint32_t)off; if (certify && !f64) off += up((size_t)max_src_n * sizeof(uint16_t));      // float64-exact mode: sc.margins
-    lay.rows_off = (uint32_t)off; off += sizeof(double) * (size_t)(rows_cap * RS > 16 ? rows_cap * RS : 16);
+    lay.margin_off = (uint32_t)off; if (certify && !f64 && !incr) off += up((size_t)max_src_n * sizeof(uint16_t));      // float64-exact mode, running sums: sc.margins
+    lay.rows_off = (uint32_t)off; off += sizeof(double) * (size_t)(incr ? kQIncrDoubles : (rows_cap * RS > 16 ? rows_cap * RS : 16));
     return up(off);
   };
   auto slots_for = [&](size_t slot_bytes) -> int {
@@ -969,14 +1196,14 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   lay.ctl_bytes = (uint32_t)up((size_t)Q * kQCtlBytes + 64 + 128 + (size_t)kIcpBatchMaxWaves * kWave * sizeof(uint16_t));
   lay.Q = Q;
   lay.G = env_int("LSLAM_ICP_QUEUE_G", 0);                     // slabs per search task; 0: one, two for problems above 32 slabs
-  if (nslabs > queue_rows(f64) * 2 * queue_row_slabs(f64)) return hipErrorInvalidValue;
+  if (nslabs > queue_rows(f64) * 2 * queue_row_slabs(f64) || nslabs > 16 * kQBaseRows) return hipErrorInvalidValue;
   lay.certify = certify ? 1 : 0;
   lay.ecap_frac = 0.25f;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_ECAP")) lay.ecap_frac = (float)atof(e);
   lay.queue = sc.queue;
   lay.margins = sc.margins;
   lay.margin_stride = (uint32_t)((max_src_n + 63) & ~(int64_t)63);
-  if (f64 && certify && (!sc.margins || (size_t)(S < cus ? S : cus) * 16 * lay.margin_stride > sc.margin_cap)) return hipErrorInvalidValue;
+  if ((f64 || incr) && certify && (!sc.margins || (size_t)(S < cus ? S : cus) * 16 * lay.margin_stride > sc.margin_cap)) return hipErrorInvalidValue;
   lay.debug = getenv("LSLAM_DEBUG") ? 1 : 0;
   const size_t smem = lay.ctl_bytes + (size_t)Q * slot;
   if (smem > kLdsPerCu) return hipErrorInvalidValue;
@@ -999,7 +1226,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
                           (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[13] / (double)(h[12] ? h[12] : 1), (double)h[13] / h[8]);
 #endif
     fprintf(stderr, "[lslam] icp_queue_kernel: %d workgroups x %d waves, %d slots of %zu B (%zu B LDS), %d rows per slot, %s\n",
-            grid, W, Q, slot, smem, rows_cap, f64 ? "float64-exact" : "float32");
+            grid, W, Q, slot, smem, rows_cap, f64 ? (incr ? "float64-exact, running sums" : "float64-exact") : (incr ? "float32, running sums" : "float32"));
   }
   hipError_t e = hipMemsetAsync(sc.queue, 0, 144, stream);
   if (e != hipSuccess) return e;
@@ -1009,8 +1236,9 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), smem, stream, a, sc, lay, S);
     return hipGetLastError();
   };
-  if (certify) return f64 ? launch(icp_queue_kernel<true, true>) : launch(icp_queue_kernel<false, true>);
-  return f64 ? launch(icp_queue_kernel<true, false>) : launch(icp_queue_kernel<false, false>);
+  if (incr) return f64 ? launch(icp_queue_kernel<true, true, true>) : launch(icp_queue_kernel<false, true, true>);
+  if (certify) return f64 ? launch(icp_queue_kernel<true, true, false>) : launch(icp_queue_kernel<false, true, false>);
+  return f64 ? launch(icp_queue_kernel<true, false, false>) : launch(icp_queue_kernel<false, false, false>);
 }
 
 }  // namespace lslam
