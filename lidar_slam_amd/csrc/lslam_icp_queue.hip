@@ -81,6 +81,9 @@ struct QueueCtl {                                      // one per slot, in LDS; 
   float extend;                                        // E of the current iteration's searches
   float ecap;                                          // cap of E for this problem
   uint32_t dirty;                                      // running-sums build: bit t = task t of this round left a row of changes
+  uint32_t rerun;                                      // … bit b = block b (Gb slabs) holds a source whose certificate may have run out: its task must look
+  float moved;                                         // … Σ of the steps' displacement bounds so far (rounded up): a source searched at `moved` = a with margin g is certified while a + g > moved
+  int32_t Gb;                                          // … slabs per block = per task after the first iteration
 };
 static_assert(sizeof(QueueCtl) <= kQCtlBytes, "control block");
 #define QCTL_DWORD(field) (int)(offsetof(QueueCtl, field) / 4)
@@ -132,7 +135,8 @@ constexpr int kQBase = 12;                             // running sums (DD each)
 constexpr int kQDelta = 7;                             // … of which the last seven depend on the matches
 constexpr int kQDeltaRows = 16;                        // tasks of a round that may leave a row of changes
 constexpr int kQBaseRows = 8;                          // tasks of the first iteration's round of sums
-constexpr int kQIncrDoubles = 2 * kQBase + (2 * kQDelta * kQDeltaRows > 2 * kQBase * kQBaseRows ? 2 * kQDelta * kQDeltaRows : 2 * kQBase * kQBaseRows);
+constexpr int kQIncrRows = 2 * kQBase + (2 * kQDelta * kQDeltaRows > 2 * kQBase * kQBaseRows ? 2 * kQDelta * kQDeltaRows : 2 * kQBase * kQBaseRows);      // doubles: the sums, then the round's rows
+constexpr int kQIncrDoubles = kQIncrRows + kQDeltaRows / 2;      // … then one float per block: the earliest expiry among its sources
 
 // A float32 source from its LDS copy or, where a slot has no room for one, from the sorted copy in memory — as two explicit
 // paths: written as one conditional expression the compiler selects between the two POINTERS and emits a flat_load (the slow
@@ -293,6 +297,15 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     else return reinterpret_cast<uint16_t*>(base + lay.margin_off);
   };
 
+  // running-sums build: a source's certificate as an EXPIRY — the value of the slot's `moved` at which it runs out — one float per source
+  // in the same scratch rows; checking a source is then a load and a compare, and nothing is written back
+  auto expiry_of = [&](int q) -> float* { return reinterpret_cast<float*>(lay.margins) + ((size_t)blockIdx.x * (size_t)Q + (size_t)q) * lay.margin_stride; };
+  auto later_group = [&](int nslabs) -> int {                // slabs per task after the first iteration: a function of the problem's size alone
+    int g = lay.G > 0 ? lay.G : (nslabs > 32 ? 8 : 4);
+    if (g * kQDeltaRows < nslabs) g = (nslabs + kQDeltaRows - 1) / kQDeltaRows;
+    return g;
+  };
+
   // ---- one wave: draw the next problem and stage it into slot q (or mark the slot empty for good) ----
   auto refill = [&](int q) {
     QueueCtl* c = ctl_of(q);
@@ -350,7 +363,11 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     }
     for (int i = lane; i < n; i += kWave) {
       sh_prev[i] = 0xffff;
-      if constexpr (CERT) sh_margin[i] = 0;
+      if constexpr (CERT && !INCR) sh_margin[i] = 0;
+    }
+    if constexpr (INCR) {
+      float* tmin = reinterpret_cast<float*>(reinterpret_cast<double*>(base + lay.rows_off) + kQIncrRows);
+      if (lane < kQDeltaRows) tmin[lane] = INFINITY;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     // the largest |p| of the cloud: what a change of the transform can move a source by (margins), the near-tie window (float64-exact mode)
@@ -383,7 +400,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       c->stop = st0; c->err = 0.0;
       c->problem = p; c->n = n; c->m = m; c->nchunks = nchunks; c->nslabs = nslabs;
       c->G = G; c->phase = 0;
-      c->done_tasks = 0; c->dirty = 0u;
+      c->done_tasks = 0; c->dirty = 0u; c->rerun = 0xffffffffu; c->moved = 0.f; c->Gb = INCR ? later_group(nslabs) : 0;
       c->Rt = sqrtf(tmax) * 1.0001f;
       c->Rs = sqrtf(smax) * 1.0001f;
       c->stepR = INFINITY; c->stepT = INFINITY;               // no earlier transform: nothing is certified in the first iteration
@@ -402,6 +419,9 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     unsigned char* base = slot_of(q);
     double* rows = reinterpret_cast<double*>(base + lay.rows_off);       // [queue_rows][RS]
     const int n = lds_load_i32(&c->n), nslabs = lds_load_i32(&c->nslabs);
+    double tn_out = 0.0, err_out = 0.0;
+    StopState st_out;
+    for (;;) {                                                 // (running-sums build: iterations in which no certificate runs out are taken here, one after the other)
     Moments mo;
     mo.n = (double)n;                                          // every source has a match: the count is the cloud's size
     for (int i = 0; i < 3; ++i) { mo.sp[i] = 0.0; mo.sq[i] = 0.0; mo.lo[i] = 0.0; mo.hi[i] = 0.0; }
@@ -529,25 +549,41 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       // from the second iteration on, with certificates: one round of fused tasks (a moment group's slabs searched, then its row)
       const bool fuse = CERT && !INCR && lay.fuse && moment_tasks(nslabs) > 1;
       int G = fuse ? moment_slabs(nslabs) : search_group(nslabs, st.executed);
-      if constexpr (INCR) {
-        // a task may leave a row of changes: at most kQDeltaRows tasks, and a grouping that depends on the problem's size alone
-        G = lay.G > 0 ? lay.G : (nslabs > 32 ? 8 : 4);
-        if (G * kQDeltaRows < nslabs) G = (nslabs + kQDeltaRows - 1) / kQDeltaRows;
-      }
+      if constexpr (INCR) G = later_group(nslabs);              // a task may leave a row of changes: at most kQDeltaRows tasks, and a grouping that depends on the problem's size alone
       clear_rows(base, nslabs);
+      // running-sums build: the blocks in which some certificate runs out before the next iteration's transform — none: nothing can
+      // change a match, the sums stand, and the next iteration is this wave's next trip through the loop
+      unsigned rerun = 0xffffffffu;
+      float moved_next = 0.f;
+      if constexpr (INCR) {
+        const float step = __builtin_fmaf(stepR, c->Rs, stepT) * 1.00002f;      // every source of the cloud moves by less
+        moved_next = next_up(c->moved + step);
+        float* tmin = reinterpret_cast<float*>(rows + kQIncrRows);
+        const int nblocks = nslabs > 0 ? (nslabs + G - 1) / G : 1;
+        const bool mine = lane < nblocks && !(tmin[lane < kQDeltaRows ? lane : 0] > moved_next);
+        rerun = stepR < INFINITY ? (unsigned)__ballot(mine) : 0xffffffffu;
+        if (stepR < INFINITY && mine) tmin[lane] = INFINITY;   // the block's task will leave the new minimum
+      }
       if (lane == 0) {
         c->stop = st; c->err = err; c->done_tasks = 0; c->dirty = 0u;
         c->G = G; c->phase = fuse ? 2 : 0;
         c->stepR = stepR; c->stepT = stepT;
+        c->rerun = rerun; c->moved = moved_next;
         // the next searches extend their reach by E ≈ kQExtend × this step (the steps of a converging run shrink geometrically:
         // margins of E / 2 then outlast what is still to come); nothing while the steps exceed what E may cost
         const float moved = stepR * c->Rs + stepT, cap = c->ecap;
         c->extend = CERT ? (kQExtend * moved <= cap ? kQExtend * moved : (moved <= cap ? cap : 0.f)) : 0.f;
       }
+      if (INCR && rerun == 0u) continue;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) open_slot(q, nslabs > 0 ? (nslabs + G - 1) / G : 1);                                    // next iteration
       return;
     }
+    tn_out = tn; err_out = err; st_out = st;
+    break;
+    }
+    const double tn = tn_out, err = err_out;
+    const StopState st = st_out;
     const int p = lds_load_i32(&c->problem);
     if (lane < 16) args.out_T[(int64_t)16 * p + lane] = tn;
     if (lane == 0) { args.out_err[p] = err; args.out_iters[p] = st.executed; }
@@ -576,6 +612,15 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     const int G = CTL_INT(cw, G);
     const int p = CTL_INT(cw, problem);
     const float stepR = CERT ? CTL_FLOAT(cw, stepR) : INFINITY, stepT = CERT ? CTL_FLOAT(cw, stepT) : INFINITY, extend = CERT ? CTL_FLOAT(cw, extend) : 0.f;
+    // running-sums build: the task's block, its sources' expiries, and how far the transform has come
+    const int blk = INCR ? (t * G) / CTL_INT(cw, Gb) : 0;
+    const float moved = INCR ? CTL_FLOAT(cw, moved) : 0.f;
+    float* __restrict__ expiry = INCR ? expiry_of(q) : nullptr;
+    float* tmin = reinterpret_cast<float*>(reinterpret_cast<double*>(base + lay.rows_off) + kQIncrRows);
+    float emin = INFINITY;                                     // the earliest expiry among this lane's sources of the task
+    if constexpr (INCR) {
+      if (stepR < INFINITY && ((CTL_INT(cw, rerun) >> blk) & 1) == 0) { QUEUE_MARK(0); return; }      // every certificate of the block outlasts this iteration
+    }
     const float2* __restrict__ gsrc = sc.src_sorted + (int64_t)p * sc.src_stride;
     const double2* __restrict__ gsrc64 = F64 ? sc.src64_sorted + (int64_t)p * sc.src_stride : nullptr;
     double T[2][4];
@@ -810,7 +855,11 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
           if constexpr (F64) slack += nt.eps0 * 1.01f;          // (the distance-proportional part of ε is inside the factors on d1 and on the step)
           mg = 0.5f * (L - d1) - slack;
         }
-        if constexpr (CERT) {                                    // kept as a half, rounded toward zero (never up)
+        if constexpr (INCR) {                                    // as an expiry, rounded down
+          const float ex = mg > 0.f ? __uint_as_float(__float_as_uint(moved + mg) - 1u) : 0.f;
+          expiry[i] = ex;
+          emin = fminf(emin, ex);
+        } else if constexpr (CERT) {                             // kept as a half, rounded toward zero (never up)
           const unsigned hb = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(mg > 0.f ? mg : 0.f, 0.f));
           sh_margin[i] = (uint16_t)(hb & 0xffffu);
         }
@@ -835,6 +884,22 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       if (u == 0 && slab < slab_hi) {
         // the margins of eight slabs at a time: their loads in flight together, the updated ones written back
         needbits = 0u;
+        if constexpr (INCR) {
+          float ev[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int ii = (slab + k) * kWave + lane;
+            ev[k] = (stepR < INFINITY && slab + k < slab_hi && ii < n) ? expiry[ii] : 0.f;
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int ii = (slab + k) * kWave + lane;
+            const bool ok = slab + k < slab_hi && ii < n;
+            const bool keep = ok && stepR < INFINITY && ev[k] > moved;
+            emin = keep ? fminf(emin, ev[k]) : emin;
+            needbits |= (ok && !keep) ? (1u << k) : 0u;
+          }
+        } else {
         uint16_t mv[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -852,6 +917,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
             sh_margin[ii] = (uint16_t)(hb & 0xffffu);
           }
           needbits |= (ok && !keep) ? (1u << k) : 0u;
+        }
         }
       }
       const bool need = owns && ((needbits >> u) & 1u) != 0u;
@@ -875,6 +941,8 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     }
     if constexpr (INCR) {
       if (task_dirty && lane == 0) atomicOr(&c->dirty, 1u << t);
+      emin = wave_min_dpp(emin);                               // (expiries are ≥ 0: their bit patterns order as they do)
+      if (lane == 0) atomicMin(reinterpret_cast<unsigned*>(&tmin[blk]), __float_as_uint(emin));
     }
     QUEUE_MARK(0);
   };
@@ -1203,7 +1271,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   lay.queue = sc.queue;
   lay.margins = sc.margins;
   lay.margin_stride = (uint32_t)((max_src_n + 63) & ~(int64_t)63);
-  if ((f64 || incr) && certify && (!sc.margins || (size_t)(S < cus ? S : cus) * 16 * lay.margin_stride > sc.margin_cap)) return hipErrorInvalidValue;
+  if ((f64 || incr) && certify && (!sc.margins || (size_t)(S < cus ? S : cus) * 16 * lay.margin_stride * (incr ? 2 : 1) > sc.margin_cap)) return hipErrorInvalidValue;
   lay.debug = getenv("LSLAM_DEBUG") ? 1 : 0;
   const size_t smem = lay.ctl_bytes + (size_t)Q * slot;
   if (smem > kLdsPerCu) return hipErrorInvalidValue;
