@@ -329,20 +329,29 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     const int nchunks = (m + CHUNK - 1) / CHUNK, nslabs = (n + kWave - 1) / kWave;
     float tmax = 0.f, smax = 0.f;
     float bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;      // the target's box
-    for (int j = lane; j < nchunks * CHUNK; j += kWave) {
-      const float2 v = (j < m) ? sc.tgt_sorted[ts + j] : make_float2(kQPad * (1.f + 0.0625f * (float)(j & 15)), 0.f);
-      *reinterpret_cast<float2*>(base + rec_off(j)) = v;
-      if ((F64 || CERT) && j < m) {
-        tmax = fmaxf(tmax, __builtin_fmaf(v.y, v.y, v.x * v.x));
-        if constexpr (CERT) { bx0 = fminf(bx0, v.x); by0 = fminf(by0, v.y); bx1 = fmaxf(bx1, v.x); by1 = fmaxf(by1, v.y); }
+    for (int j0 = 0; j0 < nchunks * CHUNK; j0 += 8 * kWave) {      // eight loads in flight per lane: one at a time, a 4096-point cloud took 64 round trips to memory
+      float2 tv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int j = j0 + u * kWave + lane; tv[u] = (j < m) ? sc.tgt_sorted[ts + j] : make_float2(kQPad * (1.f + 0.0625f * (float)(j & 15)), 0.f); }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u * kWave + lane;
+        const float2 v = tv[u];
+        if (j < nchunks * CHUNK) *reinterpret_cast<float2*>(base + rec_off(j)) = v;
+        if ((F64 || CERT) && j < m) {
+          tmax = fmaxf(tmax, __builtin_fmaf(v.y, v.y, v.x * v.x));
+          if constexpr (CERT) { bx0 = fminf(bx0, v.x); by0 = fminf(by0, v.y); bx1 = fmaxf(bx1, v.x); by1 = fmaxf(by1, v.y); }
+        }
       }
       if constexpr (F64 && !INCR) {
-        int2 d = make_int2(0, 0);
-        if (j < m) {
-          const double2 td = sc.tgt64_sorted[ts + j];
-          d = make_int2(residual_count(td.x, v.x), residual_count(td.y, v.y));
+        double2 td[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = j0 + u * kWave + lane; td[u] = (j < m) ? sc.tgt64_sorted[ts + j] : make_double2(0.0, 0.0); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * kWave + lane;
+          if (j < nchunks * CHUNK) tdelta[j] = (j < m) ? make_int2(residual_count(td[u].x, tv[u].x), residual_count(td[u].y, tv[u].y)) : make_int2(0, 0);
         }
-        tdelta[j] = d;
       }
     }
     // sources (all loads in flight before the first use), no matches and no margins yet
@@ -372,11 +381,19 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     // the largest |p| of the cloud: what a change of the transform can move a source by (margins), the near-tie window (float64-exact mode)
     if constexpr (F64 || CERT) {
-      for (int i = lane; i < n; i += kWave) {
-        float vx, vy;
-        if constexpr (F64) { const double2 pd = load_source64(src_lds, sh_src64, sc.src64_sorted + ss, i); vx = (float)pd.x; vy = (float)pd.y; }
-        else { const float2 v = load_source(src_lds, sh_src, sc.src_sorted + ss, i); vx = v.x; vy = v.y; }
-        smax = fmaxf(smax, __builtin_fmaf(vy, vy, vx * vx));
+      for (int i0 = 0; i0 < n; i0 += 8 * kWave) {              // eight loads in flight per lane
+        float2 sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * kWave + lane;
+          sv[u] = make_float2(0.f, 0.f);
+          if (i < n) {
+            if constexpr (F64) { const double2 pd = load_source64(src_lds, sh_src64, sc.src64_sorted + ss, i); sv[u] = make_float2((float)pd.x, (float)pd.y); }
+            else sv[u] = load_source(src_lds, sh_src, sc.src_sorted + ss, i);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) smax = fmaxf(smax, __builtin_fmaf(sv[u].y, sv[u].y, sv[u].x * sv[u].x));
       }
       smax = wave_max_dpp(smax);
     }
@@ -574,6 +591,9 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         const float moved = stepR * c->Rs + stepT, cap = c->ecap;
         c->extend = CERT ? (kQExtend * moved <= cap ? kQExtend * moved : (moved <= cap ? cap : 0.f)) : 0.f;
       }
+      if (INCR && lay.debug && lane == 0 && stepR < INFINITY) {
+        if (rerun) { atomicAdd(&lay.queue[3], 1u); atomicAdd(&lay.queue[32], (unsigned)__builtin_popcount(rerun)); } else atomicAdd(&lay.queue[33], 1u);
+      }
       if (INCR && rerun == 0u) continue;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) open_slot(q, nslabs > 0 ? (nslabs + G - 1) / G : 1);                                    // next iteration
@@ -743,6 +763,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         }
       }
       bool near = false;
+      float mg_tie = 0.f;                                      // float64-exact mode: the margin of a source whose near tie was decided on the float64 points
       if constexpr (F64) { near = owns && bd < kQFarD2 && sec <= near_lim(bd, nt); tie = near; }
       else tie = owns && (sec == bd || !(bd < kQFarD2));
       if constexpr (F64) {
@@ -752,16 +773,36 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         // points (lowest original index on float64 ties); chunks walked with the flagged lanes' own points and windows
         if (__any(tie || far)) {
           if (lay.debug && lane == 0) atomicAdd(&lay.queue[2], 1u);
-          const float lim = far ? INFINITY : (near ? near_lim(bd, nt) : -INFINITY);
+          // With certificates the window of a near tie is widened to the seed's reach: every target closer than that is then compared in
+          // float64 (the winner cannot change: it lies inside the narrow window), and the runner-up's exact distance gives the source a
+          // margin like any other — without one it would be searched, and walk all chunks here, in every iteration to come.
+          const float lim = far ? INFINITY : (near ? (CERT ? fmaxf(near_lim(bd, nt), dseed * dseed * 1.000002f) : near_lim(bd, nt)) : -INFINITY);
           double adx = 0.0, ady = 0.0;
           if (near || far) {
             const double2 pd = load_source64(src_lds, sh_src64, gsrc64, i);
             adx = T[0][0] * pd.x + T[0][1] * pd.y + T[0][3];
             ady = T[1][0] * pd.x + T[1][1] * pd.y + T[1][3];
           }
-          double bv = INFINITY;
+          double bv = INFINITY, bv2 = INFINITY;               // the smallest float64 distance² and the runner-up's (equal on an exact tie)
           int bo = 0x7fffffff, bp = pos;
-          for (int cc = 0; cc < nchunks; ++cc) {
+          // 64 chunk boxes at a time, one per lane, against the box of the flagged lanes' points and their widest window; the survivors
+          // one by one against every flagged lane's own point (a pass used to walk all chunks: 256 dependent LDS reads for one lane's tie)
+          const bool flagged = near || far;
+          const float fx0 = wave_min_dpp(flagged ? ax : INFINITY), fy0 = wave_min_dpp(flagged ? ay : INFINITY);
+          const float fx1 = wave_max_dpp(flagged ? ax : -INFINITY), fy1 = wave_max_dpp(flagged ? ay : -INFINITY);
+          const float flim = wave_max_dpp(lim) * 1.00002f;
+          for (int c0 = 0; c0 < nchunks; c0 += 64) {
+            bool cand = false;
+            if (c0 + lane < nchunks) {
+              const float4 b = box_at(c0 + lane);
+              const float dx = fmaxf(fmaxf(b.x - fx1, fx0 - b.z), 0.f);
+              const float dy = fmaxf(fmaxf(b.y - fy1, fy0 - b.w), 0.f);
+              cand = flim >= __builtin_fmaf(dy, dy, dx * dx);
+            }
+            unsigned long long todo = __ballot(cand);
+          while (todo) {
+            const int cc = c0 + __builtin_ctzll(todo);
+            todo &= todo - 1;
             const float4 b = box_at(cc);
             const float ox = fmaxf(fmaxf(b.x - ax, ax - b.z), 0.f);
             const float oy = fmaxf(fmaxf(b.y - ay, ay - b.w), 0.f);
@@ -775,11 +816,21 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
                 const double2 td = gtgt64[j];
                 const double dx = adx - td.x, dy = ady - td.y;
                 const double e = dx * dx + dy * dy;
-                if (e < bv || (e == bv && o < bo)) { bv = e; bo = o; bp = j; }
+                if (e < bv || (e == bv && o < bo)) { bv2 = bv; bv = e; bo = o; bp = j; }
+                else if (e < bv2) bv2 = e;
               }
             }
           }
+          }
           if (near || far) pos = bp;
+          if (CERT && near && !far && bv < (double)kQFarD2) {
+            // every target within √lim of the point was compared exactly; the others are at least dseed away as in the general case
+            const double d1 = sqrt(bv);
+            const float an = sqrtf(__builtin_fmaf(ay, ay, ax * ax));
+            const float in64 = (float)(0.5 * (sqrt(bv2) - d1) - 1e-13 * ((double)an + d1 + 1.0)) * 0.999999f;
+            const float out32 = 0.5f * (dseed * 0.99999f - (float)d1 * 1.0000003f) - (2.5e-7f * an + 1e-30f + nt.eps0 * 1.01f);
+            mg_tie = fminf(in64, out32);
+          }
         }
       } else if (__any(tie)) {
         // ---- equal minima (duplicate or equidistant points): among the targets at exactly the smallest distance the lowest
@@ -855,6 +906,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
           if constexpr (F64) slack += nt.eps0 * 1.01f;          // (the distance-proportional part of ε is inside the factors on d1 and on the step)
           mg = 0.5f * (L - d1) - slack;
         }
+        if (F64 && CERT && tie) mg = mg_tie;
         if constexpr (INCR) {                                    // as an expiry, rounded down
           const float ex = mg > 0.f ? __uint_as_float(__float_as_uint(moved + mg) - 1u) : 0.f;
           expiry[i] = ex;
@@ -1134,6 +1186,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     finish(q);
   };
 
+  const long long wg_t0 = lay.debug ? (long long)wall_clock64() : 0ll;
   // ---- first problems, then the queue ----
   for (int q = wave; q < Q; q += nwaves) refill(q);
   QUEUE_MARK(3);
@@ -1172,6 +1225,10 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
 #ifdef LSLAM_QUEUE_PROFILE
     if (__any(lane < Q && st_ == 0)) QUEUE_MARK(5); else QUEUE_MARK(4);       // [5]: idle while the workgroup's slots are draining (the queue is exhausted)
 #endif
+  }
+  if (lay.debug && tid == 0) {                                 // how evenly the workgroups finish (100 MHz ticks)
+    const unsigned life = (unsigned)((long long)wall_clock64() - wg_t0);
+    atomicMax(&lay.queue[36], life); atomicMin(&lay.queue[37], ~life); atomicAdd(&lay.queue[38], life >> 8);
   }
   QUEUE_MARK(4);
 #ifdef LSLAM_QUEUE_PROFILE
@@ -1280,23 +1337,32 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   const int threads = W * 64;
   if (lay.debug) {
     unsigned long long h[18];
+    unsigned hu_tail[2] = {0, 0};
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpy(h, sc.queue, 144, hipMemcpyDeviceToHost);
-    const unsigned* hu = reinterpret_cast<const unsigned*>(h);
-    fprintf(stderr, "[lslam] queue kernel, previous launch: problems drawn %u, timeouts %u, tie passes %u\n", hu[0], hu[1], hu[2]);
+    (void)hipMemcpy(hu_tail, sc.queue + 32, 8, hipMemcpyDeviceToHost);
+    { unsigned life[3] = {0, 0, 0}; (void)hipMemcpy(life, sc.queue + 36, 12, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[lslam] queue kernel, previous launch: workgroup lifetimes max %.1f us, min %.1f us, mean %.1f us\n", life[0] / 100.0, (~life[1]) / 100.0, life[2] * 256.0 / 100.0 / (double)cus); }
+    unsigned hu[34];
+    for (int k = 0; k < 32; ++k) hu[k] = reinterpret_cast<const unsigned*>(h)[k];
+    hu[32] = hu_tail[0]; hu[33] = hu_tail[1];
+    fprintf(stderr, "[lslam] queue kernel, previous launch: problems drawn %u, timeouts %u, tie passes %u; running sums: %u rounds of %.2f blocks after the first, %u iterations without a round\n",
+            hu[0], hu[1], hu[2], hu[3], hu[3] ? (double)hu[32] / hu[3] : 0.0, hu[33]);
 #ifdef LSLAM_QUEUE_PROFILE
     double tot = 0; for (int k = 0; k < 6; ++k) tot += (double)h[2 + k];
     if (tot > 0) fprintf(stderr, "[lslam] queue kernel, share of wave cycles: search %.3f  moments %.3f  reduce+solve %.3f  outputs+staging %.3f  idle %.3f  idle while draining %.3f\n",
                          h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot, h[7] / tot);
     if (h[8] > 0) fprintf(stderr, "[lslam] queue kernel, gathered searches: %.3f of the search cycles (%.0f ticks each); %.0f ticks of search+moment+solve per task, %llu tasks\n",
                           (double)h[14] / (double)(h[2] ? h[2] : 1), (double)h[14] / h[8], (double)(h[2] + h[3] + h[4]) / (double)(h[15] ? h[15] : 1), h[15]);
+    if (h[8] > 0) fprintf(stderr, "[lslam] queue kernel, %llu searches, %llu sources visited, %llu searched; wave cycles: search %.3g moments %.3g solve %.3g staging %.3g idle %.3g draining %.3g\n",
+                          h[8], h[12], h[13], (double)h[2], (double)h[3], (double)h[4], (double)h[5], (double)h[6], (double)h[7]);
     if (h[8] > 0) fprintf(stderr, "[lslam] queue kernel, per search of <= 64 sources: %.2f surviving boxes, %.2f list rounds, %.2f (point, chunk) entries; %.3f of the sources visited were searched (%.1f per search)\n",
                           (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[13] / (double)(h[12] ? h[12] : 1), (double)h[13] / h[8]);
 #endif
     fprintf(stderr, "[lslam] icp_queue_kernel: %d workgroups x %d waves, %d slots of %zu B (%zu B LDS), %d rows per slot, %s\n",
             grid, W, Q, slot, smem, rows_cap, f64 ? (incr ? "float64-exact, running sums" : "float64-exact") : (incr ? "float32, running sums" : "float32"));
   }
-  hipError_t e = hipMemsetAsync(sc.queue, 0, 144, stream);
+  hipError_t e = hipMemsetAsync(sc.queue, 0, 160, stream);      // (the counters of the debug print live in the first 136 bytes)
   if (e != hipSuccess) return e;
   auto launch = [&](auto kernel) -> hipError_t {
     hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
