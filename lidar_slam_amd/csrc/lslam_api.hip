@@ -154,7 +154,7 @@ static WsFence& ws_fence() { static thread_local WsFence f; return f; }
 // start anywhere), kept by the calling thread and reused by its next call; grown behind a hipDeviceSynchronize().
 struct PruneHolder {
   PruneScratch sc{};
-  size_t cap_src = 0, cap_tgt = 0, cap_src64 = 0, cap_tgt64 = 0;
+  size_t cap_src = 0, cap_tgt = 0, cap_src64 = 0, cap_tgt64 = 0, cap_order = 0;
   int device = -1;
   void release() {
     if (sc.src_sorted) (void)hipFree(sc.src_sorted);
@@ -165,6 +165,8 @@ struct PruneHolder {
     if (sc.tgt64_sorted) (void)hipFree(sc.tgt64_sorted);
     if (sc.queue) (void)hipFree(sc.queue);
     if (sc.margins) (void)hipFree(sc.margins);
+    if (sc.order) (void)hipFree(sc.order);
+    cap_order = 0;
     sc = PruneScratch{}; cap_src = cap_tgt = cap_src64 = cap_tgt64 = 0; device = -1;
   }
   int ensure(int32_t S, int64_t max_src_n, int64_t max_tgt_n, bool f64) {
@@ -191,6 +193,13 @@ struct PruneHolder {
       LSLAM_HIP_TRY(hipMalloc(&sc.src64_sorted, sizeof(double2) * need_src));
       LSLAM_HIP_TRY(hipMalloc(&sc.tgt64_sorted, sizeof(double2) * need_tgt));
       cap_src64 = need_src; cap_tgt64 = need_tgt;
+    }
+    if ((size_t)S > cap_order) {                               // the problems by class (icp_sort_kernel)
+      LSLAM_HIP_TRY(hipDeviceSynchronize());
+      if (sc.order) (void)hipFree(sc.order);
+      sc.order = nullptr; cap_order = 0;
+      LSLAM_HIP_TRY(hipMalloc(&sc.order, sizeof(int32_t) * (size_t)S));
+      cap_order = (size_t)S;
     }
     // the task-queue kernel's margins (float64-exact mode, running sums): at most 16 slots of kPruneMaxPoints sources per workgroup, one workgroup per CU
     if (!sc.margins) {

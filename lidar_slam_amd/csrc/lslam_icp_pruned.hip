@@ -254,6 +254,12 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, 
     sc.src_index[ss + i] = (uint16_t)o;
     if (a.src64) sc.src64_sorted[ss + i] = reinterpret_cast<const double2*>(a.src64)[s0 + o];
   }
+  // the problem's class (launch_icp_pruned): which kernel iterates a problem depends on its own size, not on the batch it came in
+  if (sc.order && tid == 0) {
+    const unsigned big = (n >= kQueueCertifyPoints || m >= kQueueCertifyPoints) ? 1u : 0u;
+    const unsigned k = atomicAdd(&sc.queue[48 + big], 1u);
+    sc.order[big ? (int)gridDim.x - 1 - (int)k : (int)k] = pair;
+  }
 }
 
 // F64: the float64-exact mode (lslam_device.h: NearTie; args.src64 / args.tgt64 set) — pruning and tie detection use the
@@ -794,14 +800,24 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   if (curve >= 1) g_max *= 2;
   const int cur_words = ((g_max * g_max + 64 > len ? g_max * g_max + 64 : len) + 3) & ~3;
   const size_t sort_lds = sizeof(float2) * (size_t)cap + sizeof(unsigned) * (size_t)cur_words + 2 * sizeof(uint16_t) * (size_t)cap;
-  auto sort = [&](auto kernel, int threads) -> hipError_t {
-    hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
+  // A batch that holds problems on both sides of the certificates' threshold is iterated by two launches, one per class: every bit of
+  // a problem's result then depends on the problem alone (tests/test_gpu_icp.py: …batch_independent), and the small ones get the LDS
+  // geometry of small problems.  Not when LSLAM_ICP_QUEUE_CERTIFY forces one kind of kernel on everything.
+  const bool split = sc.order && sc.queue && big >= kQueueCertifyPoints && !getenv("LSLAM_ICP_QUEUE_CERTIFY");
+  PruneScratch scs = sc;
+  if (!split) scs.order = nullptr;
+  else {
+    const hipError_t ee = hipMemsetAsync(sc.queue + 48, 0, 2 * sizeof(unsigned), stream);
     if (ee != hipSuccess) return ee;
-    hipLaunchKernelGGL(kernel, dim3(S), dim3(threads), sort_lds, stream, a, sc, len, keep, curve, cap, cur_words);
-    return hipSuccess;
-  };
+  }
   {
-    const hipError_t ee = big >= 2048 ? sort(icp_sort_kernel<512>, 512) : sort(icp_sort_kernel<256>, 256);
+    auto sort_s = [&](auto kernel, int threads) -> hipError_t {
+      hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
+      if (ee != hipSuccess) return ee;
+      hipLaunchKernelGGL(kernel, dim3(S), dim3(threads), sort_lds, stream, a, scs, len, keep, curve, cap, cur_words);
+      return hipSuccess;
+    };
+    const hipError_t ee = big >= 2048 ? sort_s(icp_sort_kernel<512>, 512) : sort_s(icp_sort_kernel<256>, 256);
     if (ee != hipSuccess) return ee;
   }
   hipError_t e = hipGetLastError();
@@ -813,7 +829,13 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   {
     bool queue = true;
     if (const char* env = getenv("LSLAM_ICP_PRUNE_QUEUE")) queue = atoi(env) != 0;
-    if (queue && sc.queue) return launch_icp_queue(a, sc, S, max_src_n, max_tgt_n, stream);
+    if (queue && sc.queue) {
+      if (!split) return launch_icp_queue(a, scs, S, max_src_n, max_tgt_n, stream);
+      const hipError_t ee = launch_icp_queue(a, scs, S, max_src_n, max_tgt_n, stream, 1);
+      if (ee != hipSuccess) return ee;
+      const int64_t cap_small = kQueueCertifyPoints - 1;
+      return launch_icp_queue(a, scs, S, max_src_n < cap_small ? max_src_n : cap_small, max_tgt_n < cap_small ? max_tgt_n : cap_small, stream, 0);
+    }
   }
   // One source per lane, and about four slabs of 64 sources per wave: a workgroup is then a quarter of the waves a problem
   // "needs", several problems share a CU (eight LiDAR-sized ones instead of three), and their barriers and one-wave solves —

@@ -312,6 +312,10 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     int p = 0;
     if (lane == 0) p = (int)atomicAdd(&lay.queue[0], 1u);
     p = __builtin_amdgcn_readfirstlane(p);
+    // (a launch over one class of problems: their number was counted by icp_sort_kernel, their indices are in `order`)
+    const int avail = lay.cls < 0 ? S : (int)__builtin_amdgcn_readfirstlane(__hip_atomic_load(&lay.queue[48 + lay.cls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (p < avail && lay.cls >= 0) p = __builtin_amdgcn_readfirstlane(lay.order[lay.cls ? S - 1 - p : p]);
+    else if (p >= avail) p = S;
     if (p >= S) {
       if (lane == 0) __hip_atomic_store(&states[q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // the ticket stays closed
       return;
@@ -1246,7 +1250,7 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n, hipStream_t stream) {
+hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n, hipStream_t stream, int cls) {
   if ((a.src64 == nullptr) != (a.tgt64 == nullptr)) return hipErrorInvalidValue;
   const bool f64 = a.src64 != nullptr;
   const bool box = (a.flags & kFlagNormalize) != 0;
@@ -1269,8 +1273,9 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   // Certificates pay once a run has iterations in which little moves (C4, 50 iterations: 4 % of the source visits still search, 16.6
   // -> 6.9 ms); a LiDAR-sized pair stops after ~6 iterations, the sources it could skip in the last of them are scattered over all
   // slabs, and the margins cost a slot of LDS (C3: 0.72 -> 0.85 ms): from 2048 points per cloud by default.
-  bool certify = max_src_n >= 2048 || max_tgt_n >= 2048;
+  bool certify = max_src_n >= kQueueCertifyPoints || max_tgt_n >= kQueueCertifyPoints;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_CERTIFY")) certify = atoi(e) != 0;
+  if (cls >= 0 && !sc.order) return hipErrorInvalidValue;
   // running sums instead of a pass over all pairs per iteration (see finish): with certificates, unless the normalised error's box is asked for
   const bool incr = certify && !box && env_int("LSLAM_ICP_QUEUE_INCR", 1) != 0;
   const int rows_cap = queue_rows(f64);
@@ -1326,6 +1331,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   lay.ecap_frac = 0.25f;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_ECAP")) lay.ecap_frac = (float)atof(e);
   lay.queue = sc.queue;
+  lay.cls = cls; lay.order = sc.order;
   lay.margins = sc.margins;
   lay.margin_stride = (uint32_t)((max_src_n + 63) & ~(int64_t)63);
   if ((f64 || incr) && certify && (!sc.margins || (size_t)(S < cus ? S : cus) * 16 * lay.margin_stride * (incr ? 2 : 1) > sc.margin_cap)) return hipErrorInvalidValue;
