@@ -401,11 +401,11 @@ def main():
             ms_p = _time(torch, step_auto, 2, a.steps)
             ev_p = _time_events(torch, step_auto, 1, a.steps)
             result["default_search_strategy"] = {"what": "same workload, search strategy left to the library (flags = 0): spatially ordered clouds + exact box pruning in the task-queue kernel "
-                                                         "(icp_sort_kernel + icp_queue_kernel; sources keep their match while a proof allows it), identical correspondences and iteration counts",
+                                                         "(icp_sort_kernel + icp_queue_kernel; sources keep their match while a proof allows it, the moments are running double-double sums updated by the matches that change, and iterations in which no proof runs out cost one solve), identical correspondences and iteration counts",
                                                  "ms_per_step": ms_p, "icp_iterations_per_sec": S * I / (ms_p * 1e-3),
                                                  "speedup_vs_all_pairs_sweep": (dt / a.steps * 1e3) / ms_p,
                                                  "max_abs_T_difference": float((oT2 - out_T).abs().max().item()),
-                                                 "roofline": kernel_roofline("c4_default_search_strategy", "icp_queue_kernel<false,true>", ev_p, pair_evals_per_launch, 5,
+                                                 "roofline": kernel_roofline("c4_default_search_strategy", "icp_queue_kernel<false,true,true>", ev_p, pair_evals_per_launch, 5,
                                                                              "event time covers icp_sort_kernel + icp_queue_kernel; exact pruning + certificates: the N x M pair evaluations are what the launch is equivalent to, not what it executes")}
         if rank == 0 and world == 1:
             # float64-exact mode (what run_icp / poses_from_scan_matching use): the same clouds also resident in float64; near
@@ -428,8 +428,8 @@ def main():
                                             "max_abs_T_difference_to_float32_mode": d_default,
                                             "roofline_all_pairs": kernel_roofline("c4_float64_exact_all_pairs", "icp_batch_filter_kernel<2,4,true>", ev_f64_all, pair_evals_per_launch, 5,
                                                                                   "the headline's sweep with near ties decided and moments accumulated on the float64 points (kept on chip as int32 residuals beside the float32 copies); 4 points per lane: the 8-point build of this mode has no LDS left for the residuals (DESIGN.md 3.1d)"),
-                                            "roofline_default_strategy": kernel_roofline("c4_float64_exact_default", "icp_queue_kernel<true,true>", ev_f64_default, pair_evals_per_launch, 5,
-                                                                                         "icp_sort_kernel + icp_queue_kernel in float64-exact mode: one problem per CU (145 KB of LDS: float64 sources, float32 targets + residuals)"),
+                                            "roofline_default_strategy": kernel_roofline("c4_float64_exact_default", "icp_queue_kernel<true,true,true>", ev_f64_default, pair_evals_per_launch, 5,
+                                                                                         "icp_sort_kernel + icp_queue_kernel in float64-exact mode: three problems per CU as in float32 mode (running sums: the float64 points are read only where a match changes, from the sorted copies in memory)"),
                                             "note": "the synthetic clouds are float32-representable, so both modes see the same points; the difference is the float32 recipe's rounding of near ties"}
             del src64, tgt64
         if rank == 0 and world == 1 and a.natural:
@@ -712,9 +712,9 @@ def other_config(name, a, torch, device, stream, timed):
         out = {"workload": "C3 dataset-20-like sequence: 4955 consecutive scan pairs (650-1081 pts), natural convergence, host arrays in/out (PCIe + chain included)",
                "stage_seconds": stage_s, "stage_seconds_first_call": first_s, "stage_seconds_float32_scans": stage32_s,
                "kernel_seconds_scans_resident": kern64_ms * 1e-3, "kernel_seconds_scans_resident_float32": kern32_ms * 1e-3,
-               "roofline": kernel_roofline("c3_float64_exact", "icp_queue_kernel<true,false>", ev64, evals, 5,
+               "roofline": kernel_roofline("c3_float64_exact", "icp_queue_kernel<true,false,false>", ev64, evals, 5,
                                            "icp_sort_kernel (order test + copies) + icp_queue_kernel over the 4955 LiDAR-sized pairs to natural convergence, float64-exact mode (what the Python surface runs); exact pruning: equivalent pair evaluations"),
-               "roofline_float32": kernel_roofline("c3_float32", "icp_queue_kernel<false,false>", ev32, evals, 5, "same sequence, float32 scans"),
+               "roofline_float32": kernel_roofline("c3_float32", "icp_queue_kernel<false,false,false>", ev32, evals, 5, "same sequence, float32 scans"),
                "iteration_counts_differ_float32_vs_float64_exact": int(np.sum(info.iterations != info32.iterations)),
                "max_rel_pose_difference_float32_vs_float64_exact": float(np.abs(rel - rel32).max()),
                "scan_pairs_per_sec": 4955 / stage_s, "total_iterations": int(info.iterations.sum()),

@@ -57,6 +57,9 @@ namespace lslam {
 constexpr int kQCtlBytes = 256;
 constexpr long long kQTimeoutTicks = 400000000ll;      // 4 s of the 100 MHz wall clock
 constexpr int kQRec = kPruneChunk * 8 + 16;            // bytes per chunk record: 16 targets + the chunk's box
+#ifndef QEXP_STAGE
+#define QEXP_STAGE 8
+#endif
 #ifndef QEXP_F64ROWS
 #define QEXP_F64ROWS 8
 #endif
@@ -131,6 +134,7 @@ __device__ __forceinline__ DD wave_sum_dd_last(DD v) {          // the sum over 
   dd_dpp_step<kDppMirror, 0xf>(v); dd_dpp_step<kDppBcast15, 0xa>(v); dd_dpp_step<kDppBcast31, 0xc>(v);
   return v;
 }
+constexpr int kQStage = QEXP_STAGE;                     // loads a lane keeps in flight while a problem is staged
 constexpr int kQBase = 12;                             // running sums (DD each): Σx Σy Σxx Σxy Σyy of the sources | Σqx Σqy | Σx·qx Σx·qy Σy·qx Σy·qy | Σ|q|² of the matches
 constexpr int kQDelta = 7;                             // … of which the last seven depend on the matches
 constexpr int kQDeltaRows = 16;                        // tasks of a round that may leave a row of changes
@@ -333,12 +337,12 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     const int nchunks = (m + CHUNK - 1) / CHUNK, nslabs = (n + kWave - 1) / kWave;
     float tmax = 0.f, smax = 0.f;
     float bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;      // the target's box
-    for (int j0 = 0; j0 < nchunks * CHUNK; j0 += 8 * kWave) {      // eight loads in flight per lane: one at a time, a 4096-point cloud took 64 round trips to memory
-      float2 tv[8];
+    for (int j0 = 0; j0 < nchunks * CHUNK; j0 += kQStage * kWave) {      // eight loads in flight per lane: one at a time, a 4096-point cloud took 64 round trips to memory
+      float2 tv[kQStage];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int j = j0 + u * kWave + lane; tv[u] = (j < m) ? sc.tgt_sorted[ts + j] : make_float2(kQPad * (1.f + 0.0625f * (float)(j & 15)), 0.f); }
+      for (int u = 0; u < kQStage; ++u) { const int j = j0 + u * kWave + lane; tv[u] = (j < m) ? sc.tgt_sorted[ts + j] : make_float2(kQPad * (1.f + 0.0625f * (float)(j & 15)), 0.f); }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kQStage; ++u) {
         const int j = j0 + u * kWave + lane;
         const float2 v = tv[u];
         if (j < nchunks * CHUNK) *reinterpret_cast<float2*>(base + rec_off(j)) = v;
@@ -348,13 +352,16 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         }
       }
       if constexpr (F64 && !INCR) {
-        double2 td[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int j = j0 + u * kWave + lane; td[u] = (j < m) ? sc.tgt64_sorted[ts + j] : make_double2(0.0, 0.0); }
+        for (int h = 0; h < kQStage; h += 4) {                       // (four float64 points in flight: eight spill)
+          double2 td[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 + u * kWave + lane;
-          if (j < nchunks * CHUNK) tdelta[j] = (j < m) ? make_int2(residual_count(td[u].x, tv[u].x), residual_count(td[u].y, tv[u].y)) : make_int2(0, 0);
+          for (int u = 0; u < 4; ++u) { const int j = j0 + (h + u) * kWave + lane; td[u] = (j < m) ? sc.tgt64_sorted[ts + j] : make_double2(0.0, 0.0); }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = j0 + (h + u) * kWave + lane;
+            if (j < nchunks * CHUNK) tdelta[j] = (j < m) ? make_int2(residual_count(td[u].x, tv[h + u].x), residual_count(td[u].y, tv[h + u].y)) : make_int2(0, 0);
+          }
         }
       }
     }
@@ -1190,7 +1197,9 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     finish(q);
   };
 
+#ifdef LSLAM_QUEUE_PROFILE
   const long long wg_t0 = lay.debug ? (long long)wall_clock64() : 0ll;
+#endif
   // ---- first problems, then the queue ----
   for (int q = wave; q < Q; q += nwaves) refill(q);
   QUEUE_MARK(3);
@@ -1230,12 +1239,12 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     if (__any(lane < Q && st_ == 0)) QUEUE_MARK(5); else QUEUE_MARK(4);       // [5]: idle while the workgroup's slots are draining (the queue is exhausted)
 #endif
   }
-  if (lay.debug && tid == 0) {                                 // how evenly the workgroups finish (100 MHz ticks)
-    const unsigned life = (unsigned)((long long)wall_clock64() - wg_t0);
-    atomicMax(&lay.queue[36], life); atomicMin(&lay.queue[37], ~life); atomicAdd(&lay.queue[38], life >> 8);
-  }
   QUEUE_MARK(4);
 #ifdef LSLAM_QUEUE_PROFILE
+  if (lay.debug && tid == 0) {                                 // how evenly the workgroups finish (100 MHz ticks)
+    const unsigned life = (unsigned)((long long)wall_clock64() - wg_t0);
+    atomicMax(&lay.queue[36], life); atomicAdd(&lay.queue[38], life >> 8);
+  }
   // cycles per phase and search statistics summed over the waves of the launch (printed by the launcher under LSLAM_DEBUG)
   if (lay.debug && lane == 0) {
     for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(lay.queue + 4) + k, prof[k]);
@@ -1347,8 +1356,10 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpy(h, sc.queue, 144, hipMemcpyDeviceToHost);
     (void)hipMemcpy(hu_tail, sc.queue + 32, 8, hipMemcpyDeviceToHost);
+#ifdef LSLAM_QUEUE_PROFILE
     { unsigned life[3] = {0, 0, 0}; (void)hipMemcpy(life, sc.queue + 36, 12, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[lslam] queue kernel, previous launch: workgroup lifetimes max %.1f us, min %.1f us, mean %.1f us\n", life[0] / 100.0, (~life[1]) / 100.0, life[2] * 256.0 / 100.0 / (double)cus); }
+      fprintf(stderr, "[lslam] queue kernel, previous launch: workgroup lifetimes max %.1f us, mean %.1f us\n", life[0] / 100.0, life[2] * 256.0 / 100.0 / (double)cus); }
+#endif
     unsigned hu[34];
     for (int k = 0; k < 32; ++k) hu[k] = reinterpret_cast<const unsigned*>(h)[k];
     hu[32] = hu_tail[0]; hu[33] = hu_tail[1];

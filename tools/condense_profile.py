@@ -51,12 +51,12 @@ c4_f64 = c4_f32 + 2 * S * P * 16                           # + both float64 clou
 #  take only the launches at least this long in ms (0: all) — a workload may launch the same kernel for warm-ups on tiny inputs)
 ENTRIES = [
     ("c4", "c4", "icp_batch_filter_kernel<2, 8, false>", pair_evals, c4_f32, 50),
-    ("c4_default_search_strategy", "c4", "icp_queue_kernel<false, true>", pair_evals, c4_f32, 1),
+    ("c4_default_search_strategy", "c4", "icp_queue_kernel<false, true, true>", pair_evals, c4_f32, 1),
     ("c4_float64_exact_all_pairs", "c4", "icp_batch_filter_kernel<2, 4, true>", pair_evals, c4_f64, 50),
-    ("c4_float64_exact_default", "c4", "icp_queue_kernel<true, true>", pair_evals, c4_f64, 1),
+    ("c4_float64_exact_default", "c4", "icp_queue_kernel<true, true, true>", pair_evals, c4_f64, 1),
     ("c4_sort", "c4", "icp_sort_kernel", None, None, 0),
-    ("c3_float64_exact", "c3", "icp_queue_kernel<true, false>", None, None, 0.3),
-    ("c3_float32", "c3", "icp_queue_kernel<false, false>", None, None, 0.3),
+    ("c3_float64_exact", "c3", "icp_queue_kernel<true, false, false>", None, None, 0.3),
+    ("c3_float32", "c3", "icp_queue_kernel<false, false, false>", None, None, 0.3),
     ("c3_sort", "c3", "icp_sort_kernel", None, None, 0.02),
     ("c5_all_pairs", "c5", "nn_tiled_filter_kernel<3, 4, false>", 1e10, None, 0),
     ("c5_default_search_strategy", "c5", "nn_pruned_kernel<3, 1, false>", 1e10, None, 0),
