@@ -1176,13 +1176,15 @@ def test_release_thread_resources_and_continue(icp, prec):
 # ---- the task-queue kernel (csrc/lslam_icp_queue.hip): slots, tasks and matches kept on a proof ------------------------------------
 @pytest.mark.parametrize("knobs", [{}, {"LSLAM_ICP_QUEUE_CERTIFY": "1"}, {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_Q": "1", "LSLAM_ICP_QUEUE_WAVES": "3", "LSLAM_ICP_QUEUE_G": "5"},
                                    {"LSLAM_ICP_QUEUE_CERTIFY": "0", "LSLAM_ICP_QUEUE_Q": "2", "LSLAM_ICP_QUEUE_WAVES": "16"}, {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_ECAP": "4.0"},
-                                   {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_LEAN_BELOW": "99"}, {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_FUSE": "0"}])
+                                   {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_LEAN_BELOW": "99"}, {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_FUSE": "0"},
+                                   {"LSLAM_ICP_QUEUE_INCR": "0"}, {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_INCR": "0", "LSLAM_ICP_QUEUE_G": "3"}])
 def test_task_queue_kernel_gives_the_all_pairs_answers(icp, prec, knobs, monkeypatch):
     """ragged planar batch from one point to 4096 per cloud — more problems than a CU has slots, tiny and large ones mixed, duplicates, a
     lattice, motions far from the start, many forced iterations (so that most sources hold a certificate most of the time), the normalised
     error's bounding box — through the pruned path in several geometries (slots, waves, slabs per task, certificates forced on / off, a reach
-    extension far beyond its default cap, sources read from memory instead of LDS): identical correspondences and iteration counts as the
-    all-pairs sweep, T and error to float64 summation order"""
+    extension far beyond its default cap, sources read from memory instead of LDS, running sums on / off — by default the problems from
+    2048 points per cloud run on double-double sums of changes and the smaller ones in a launch of their own): identical correspondences
+    and iteration counts as the all-pairs sweep, T and error to float64 summation order"""
     from lidar_slam_amd.batch import icp_batch
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
