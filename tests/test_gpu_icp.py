@@ -1215,6 +1215,34 @@ def test_task_queue_kernel_gives_the_all_pairs_answers(icp, prec, knobs, monkeyp
         np.testing.assert_allclose(b.error[ok], a.error[ok], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("incr", ["1", "0"])
+def test_task_queue_certificates_on_clouds_made_of_near_ties(icp, prec, incr, monkeypatch):
+    """certificates and running sums forced on for clouds in which EVERY source has four candidates the float32 search cannot tell apart
+    (lattice + nanometre perturbations, as in test_float64_exact_mode_on_clouds_made_of_near_ties), a start off the solution and twenty
+    forced iterations: a near tie decided on the float64 points gets its margin from the exact runner-up, an exact tie none — the
+    correspondences of every iteration must still be the all-pairs sweep's (the last ones are compared, and T, error and iteration count
+    depend on all of them)"""
+    from lidar_slam_amd.batch import icp_batch
+    monkeypatch.setenv("LSLAM_ICP_QUEUE_CERTIFY", "1")
+    monkeypatch.setenv("LSLAM_ICP_QUEUE_INCR", incr)
+    rng = np.random.default_rng(99)
+    g = np.stack(np.meshgrid(np.arange(40), np.arange(40)), -1).reshape(-1, 2) * 0.5 + 7.0
+    srcs, tgts, inits = [], [], []
+    for scale, th, sh in ((1e-9, 0.0, 0.0), (1e-7, 0.004, 0.01), (1e-6, -0.01, 0.03), (1e-4, 0.02, -0.05)):
+        tgts.append(g[rng.permutation(g.shape[0])] + rng.uniform(-1, 1, g.shape) * scale)
+        srcs.append(g[rng.integers(0, g.shape[0], 1300)] + 0.25 + rng.uniform(-1, 1, (1300, 2)) * scale)
+        T0 = np.eye(4); T0[:2, :2] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]; T0[:2, 3] = sh
+        inits.append(T0)
+    fs, so = prec.pack(srcs); ft, to = prec.pack(tgts)
+    kw = dict(epsilon=0.0, stopping_thresh=0.0, max_iters=19, return_correspondences=True)
+    a = icp_batch(fs, so, ft, to, np.stack(inits), prune=False, **kw)
+    b = icp_batch(fs, so, ft, to, np.stack(inits), prune=True, **kw)
+    np.testing.assert_array_equal(b.iterations, a.iterations)
+    np.testing.assert_array_equal(b.correspondences, a.correspondences)
+    np.testing.assert_allclose(b.T, a.T, atol=1e-9)
+    np.testing.assert_allclose(b.error, a.error, rtol=1e-9, atol=1e-12)
+
+
 def test_task_queue_kernel_is_bitwise_reproducible_and_batch_independent(icp, prec):
     """the same pairs solved twice, alone, and in the middle of another batch: every bit of T, error and iteration count equal — the
     grouping of the float64 partial sums depends on a problem's size only (what the sharded driver relies on)"""
