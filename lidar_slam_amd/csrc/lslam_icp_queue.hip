@@ -432,10 +432,12 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       c->Rt = sqrtf(tmax) * 1.0001f;
       c->Rs = sqrtf(smax) * 1.0001f;
       c->stepR = INFINITY; c->stepT = INFINITY;               // no earlier transform: nothing is certified in the first iteration
-      c->extend = 0.f;
       // E is capped at a fraction of the targets' mean spacing (what the extended reach costs grows with E / spacing)
       const float area = CERT ? fmaxf(bx1 - bx0, 0.f) * fmaxf(by1 - by0, 0.f) : 0.f;
       c->ecap = CERT ? lay.ecap_frac * sqrtf(area / (float)(m > 0 ? m : 1)) : 0.f;
+      // the first searches extend their reach by a share of the cap: their margins then outlast a first step of that size (without it a
+      // source whose seed is already its nearest target leaves the first iteration with no margin at all)
+      c->extend = CERT ? lay.e0_frac * c->ecap : 0.f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) open_slot(q, nslabs > 0 ? (nslabs + G - 1) / G : 1);
@@ -1339,6 +1341,8 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   lay.certify = certify ? 1 : 0;
   lay.ecap_frac = 0.25f;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_ECAP")) lay.ecap_frac = (float)atof(e);
+  lay.e0_frac = 1.f;                                         // C4: 2.81 -> 2.58 ms (float64-exact 3.25 -> 3.08); flat from 1 to 3
+  if (const char* e = getenv("LSLAM_ICP_QUEUE_E0")) lay.e0_frac = (float)atof(e);
   lay.queue = sc.queue;
   lay.cls = cls; lay.order = sc.order;
   lay.margins = sc.margins;
