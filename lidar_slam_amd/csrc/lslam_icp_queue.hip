@@ -449,6 +449,36 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     unsigned char* base = slot_of(q);
     double* rows = reinterpret_cast<double*>(base + lay.rows_off);       // [queue_rows][RS]
     const int n = lds_load_i32(&c->n), nslabs = lds_load_i32(&c->nslabs);
+    // running-sums build: the sums after this round — the first iteration's rows, or the rows of changes the searches left (the sums do not
+    // change in the iterations this wave takes by itself below: taken once, ahead of the loop)
+    double B[kQBase];
+    for (int kk = 0; kk < kQBase; ++kk) B[kk] = 0.0;
+    double* sums = rows;                                       // [kQBase] DD
+    if constexpr (INCR) {
+    double* drow = rows + 2 * kQBase;                        // the rows the round's tasks left
+    const bool full = !(__int_as_float(lds_load_i32(reinterpret_cast<const int32_t*>(&c->stepR))) < INFINITY);
+    const int k = lane < kQBase ? lane : 0;
+    DD v;
+    if (full) {
+      const int nt = base_tasks(nslabs);
+      v = DD{drow[2 * k], drow[2 * k + 1]};
+      for (int r = 1; r < nt; ++r) dd_add(v, DD{drow[(size_t)r * 2 * kQBase + 2 * k], drow[(size_t)r * 2 * kQBase + 2 * k + 1]});
+    } else {
+      v = DD{sums[2 * k], sums[2 * k + 1]};
+      unsigned dirty = lds_load_u32(&c->dirty);
+      const int kd = k - (kQBase - kQDelta);
+      while (dirty) {                                        // task order: which wave ran which task does not matter
+        const int t = __builtin_ctz(dirty);
+        dirty &= dirty - 1u;
+        if (kd >= 0) dd_add(v, DD{drow[(size_t)t * 2 * kQDelta + 2 * kd], drow[(size_t)t * 2 * kQDelta + 2 * kd + 1]});
+      }
+    }
+    { double s_, e_; two_sum(v.hi, v.lo, s_, e_); v.hi = s_; v.lo = e_; }      // hi = the sum rounded to a double
+    if (lane < kQBase) { sums[2 * lane] = v.hi; sums[2 * lane + 1] = v.lo; }
+#pragma unroll
+    for (int kk = 0; kk < kQBase; ++kk)
+      B[kk] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.hi), kk), __builtin_amdgcn_readlane(__double2loint(v.hi), kk));
+    }
     double tn_out = 0.0, err_out = 0.0;
     StopState st_out;
     for (;;) {                                                 // (running-sums build: iterations in which no certificate runs out are taken here, one after the other)
@@ -465,32 +495,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       // ones add the changes their searches found (search_points).  The last formula cancels (terms ~ n·r², result ~ n·residual²), so
       // the sums are kept as double-doubles and the 25 products are formed exactly: the error is that of the exact sum for this T —
       // closer to it than a per-pair pass in float64 — and the per-iteration pass over all pairs is gone.
-      double* sums = rows;                                     // [kQBase] DD
-      double* drow = rows + 2 * kQBase;                        // the rows the round's tasks left
-      scratch = drow;
-      const bool full = !(__int_as_float(lds_load_i32(reinterpret_cast<const int32_t*>(&c->stepR))) < INFINITY);
-      const int k = lane < kQBase ? lane : 0;
-      DD v;
-      if (full) {
-        const int nt = base_tasks(nslabs);
-        v = DD{drow[2 * k], drow[2 * k + 1]};
-        for (int r = 1; r < nt; ++r) dd_add(v, DD{drow[(size_t)r * 2 * kQBase + 2 * k], drow[(size_t)r * 2 * kQBase + 2 * k + 1]});
-      } else {
-        v = DD{sums[2 * k], sums[2 * k + 1]};
-        unsigned dirty = lds_load_u32(&c->dirty);
-        const int kd = k - (kQBase - kQDelta);
-        while (dirty) {                                        // task order: which wave ran which task does not matter
-          const int t = __builtin_ctz(dirty);
-          dirty &= dirty - 1u;
-          if (kd >= 0) dd_add(v, DD{drow[(size_t)t * 2 * kQDelta + 2 * kd], drow[(size_t)t * 2 * kQDelta + 2 * kd + 1]});
-        }
-      }
-      { double s_, e_; two_sum(v.hi, v.lo, s_, e_); v.hi = s_; v.lo = e_; }      // hi = the sum rounded to a double
-      if (lane < kQBase) { sums[2 * lane] = v.hi; sums[2 * lane + 1] = v.lo; }
-      double B[kQBase];
-#pragma unroll
-      for (int kk = 0; kk < kQBase; ++kk)
-        B[kk] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.hi), kk), __builtin_amdgcn_readlane(__double2loint(v.hi), kk));
+      scratch = rows + 2 * kQBase;
       const double T00 = c->T[0], T01 = c->T[1], T03 = c->T[3], T10 = c->T[4], T11 = c->T[5], T13 = c->T[7];
       mo.sp[0] = T00 * B[0] + T01 * B[1] + T03 * mo.n; mo.sp[1] = T10 * B[0] + T11 * B[1] + T13 * mo.n;
       mo.sq[0] = B[5]; mo.sq[1] = B[6];
@@ -562,13 +567,19 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     // how far the new transform can move a source p: ‖ΔR‖₂·|p| + |Δt|, rounded up
     float stepR = INFINITY, stepT = INFINITY;
     if constexpr (CERT) {
-      const double dl = tn - told;
-      auto at = [&](int k) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dl), k), __builtin_amdgcn_readlane(__double2loint(dl), k)); };
-      const double d00 = at(0), d01 = at(1), d03 = at(3), d10 = at(4), d11 = at(5), d13 = at(7);
+      // the differences in float64 (the entries agree to many digits), the norms in float32 — scaled by the largest entry so that nothing
+      // underflows, and rounded up by far more (1e-5) than float32 arithmetic on numbers of size one can lose
+      const float dl = fabsf((float)(tn - told));
+      auto at = [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl), k)); };
+      const float sR = fmaxf(fmaxf(at(0), at(1)), fmaxf(at(4), at(5))), sT = fmaxf(at(3), at(7));
+      const float sd = (float)(tn - told);
+      auto sg = [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sd), k)); };
+      const float iR = sR > 0.f ? 1.f / sR : 0.f, iT = sT > 0.f ? 1.f / sT : 0.f;
+      const float d00 = sg(0) * iR, d01 = sg(1) * iR, d10 = sg(4) * iR, d11 = sg(5) * iR, d03 = sg(3) * iT, d13 = sg(7) * iT;
       // the largest singular value of the 2 x 2 block ΔR (for a pure rotation step: 2 sin(Δθ/2), a factor √2 below the Frobenius norm)
-      const double f2 = d00 * d00 + d01 * d01 + d10 * d10 + d11 * d11, g1 = d00 * d00 + d01 * d01 - d10 * d10 - d11 * d11, g2 = d00 * d10 + d01 * d11;
-      stepR = (float)(sqrt(0.5 * (f2 + sqrt(g1 * g1 + 4.0 * g2 * g2))) * 1.000001) + 1e-30f;
-      stepT = (float)(sqrt(d03 * d03 + d13 * d13) * 1.000001) + 1e-30f;
+      const float f2 = d00 * d00 + d01 * d01 + d10 * d10 + d11 * d11, g1 = d00 * d00 + d01 * d01 - d10 * d10 - d11 * d11, g2 = d00 * d10 + d01 * d11;
+      stepR = sqrtf(0.5f * (f2 + sqrtf(g1 * g1 + 4.f * g2 * g2))) * sR * 1.00001f + 1e-30f;
+      stepT = sqrtf(d03 * d03 + d13 * d13) * sT * 1.00001f + 1e-30f;
     }
     const double err = error_from_moments(mo, box);
     StopState st = c->stop;
