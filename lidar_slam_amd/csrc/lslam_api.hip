@@ -206,7 +206,7 @@ struct PruneHolder {
       int cus = 0;
       LSLAM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
       if (cus <= 0) cus = 256;
-      sc.margin_cap = (size_t)cus * 16 * (size_t)kPruneMaxPoints * 2;      // in halves; the running-sums build keeps a float per source
+      sc.margin_cap = (size_t)cus * 16 * (size_t)kPruneMaxPoints * 3;      // in halves; the running-sums build keeps a float and a match per source
       LSLAM_HIP_TRY(hipMalloc(&sc.margins, sizeof(uint16_t) * sc.margin_cap));
     }
     sc.src_stride = max_src_n; sc.tgt_stride = max_tgt_n;

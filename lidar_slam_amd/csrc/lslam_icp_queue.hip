@@ -303,7 +303,13 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
 
   // running-sums build: a source's certificate as an EXPIRY — the value of the slot's `moved` at which it runs out — one float per source
   // in the same scratch rows; checking a source is then a load and a compare, and nothing is written back
-  auto expiry_of = [&](int q) -> float* { return reinterpret_cast<float*>(lay.margins) + ((size_t)blockIdx.x * (size_t)Q + (size_t)q) * lay.margin_stride; };
+  // (a slot's row of the scratch buffer in that build: margin_stride floats of expiries, then margin_stride uint16 of matches — the matches
+  // left LDS as well, so that a fourth 4096-point problem fits a CU)
+  auto expiry_of = [&](int q) -> float* { return reinterpret_cast<float*>(lay.margins + ((size_t)blockIdx.x * (size_t)Q + (size_t)q) * (size_t)lay.margin_stride * 3); };
+  auto prevs_of = [&](int q, unsigned char* base) -> uint16_t* {
+    if constexpr (INCR) return lay.margins + ((size_t)blockIdx.x * (size_t)Q + (size_t)q) * (size_t)lay.margin_stride * 3 + (size_t)lay.margin_stride * 2;
+    else return reinterpret_cast<uint16_t*>(base + lay.prev_off);
+  };
   auto later_group = [&](int nslabs) -> int {                // slabs per task after the first iteration: a function of the problem's size alone
     int g = lay.G > 0 ? lay.G : (nslabs > 32 ? 8 : 4);
     if (g * kQDeltaRows < nslabs) g = (nslabs + kQDeltaRows - 1) / kQDeltaRows;
@@ -328,7 +334,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     int2* tdelta = reinterpret_cast<int2*>(base + lay.tdelta_off);
     float2* sh_src = reinterpret_cast<float2*>(base + lay.src_off);
     double2* sh_src64 = reinterpret_cast<double2*>(base + lay.src_off);
-    uint16_t* sh_prev = reinterpret_cast<uint16_t*>(base + lay.prev_off);
+    uint16_t* sh_prev = prevs_of(q, base);
     uint16_t* sh_margin = margins_of(q, base);
     const bool src_lds = lay.src_off != 0xffffffffu;
     const int64_t s0 = args.src_off[p], t0 = args.tgt_off[p];
@@ -382,7 +388,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       }
     }
     for (int i = lane; i < n; i += kWave) {
-      sh_prev[i] = 0xffff;
+      if constexpr (!INCR) sh_prev[i] = 0xffff;                 // (running sums: the first iteration does not look at the matches)
       if constexpr (CERT && !INCR) sh_margin[i] = 0;
     }
     if constexpr (INCR) {
@@ -634,7 +640,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     if (args.out_corr) {                                       // correspondences of the LAST iteration (icp.py:117, 187-189), caller's numbering
       const int64_t s0 = args.src_off[p];
       const int64_t ss = (int64_t)p * sc.src_stride, ts = (int64_t)p * sc.tgt_stride;
-      const uint16_t* sh_prev = reinterpret_cast<const uint16_t*>(base + lay.prev_off);
+      const uint16_t* sh_prev = prevs_of(q, base);
       for (int i = lane; i < n; i += kWave) args.out_corr[s0 + sc.src_index[ss + i]] = sc.tgt_index[ts + sh_prev[i]];
     }
     refill(q);
@@ -647,7 +653,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     unsigned char* base = slot_of(q);
     const float2* sh_src = reinterpret_cast<const float2*>(base + lay.src_off);
     const double2* sh_src64 = reinterpret_cast<const double2*>(base + lay.src_off);
-    uint16_t* sh_prev = reinterpret_cast<uint16_t*>(base + lay.prev_off);
+    uint16_t* sh_prev = prevs_of(q, base);
     uint16_t* sh_margin = margins_of(q, base);
     uint16_t* gathered = reinterpret_cast<uint16_t*>(smem + (size_t)Q * kQCtlBytes + 192) + wave * kWave;      // this wave's list of sources to search
     const bool src_lds = lay.src_off != 0xffffffffu;
@@ -717,7 +723,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       int pos = 0, own = -1, pv = 0xffff;
       bool tie = false;
       if (owns) {
-        pv = sh_prev[i];
+        pv = (INCR && !(stepR < INFINITY)) ? 0xffff : (int)sh_prev[i];
         own = (pv != 0xffff ? pv : (int)(((long long)i * m) / n)) / CHUNK;
         queue_eval_chunk<F64 || CERT>(tile0, own, ax, ay, bd, sec, pos);
       }
@@ -1032,7 +1038,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
 #endif
       QueueCtl* c = ctl_of(q);
       unsigned char* base = slot_of(q);
-      const uint16_t* sh_prev = reinterpret_cast<const uint16_t*>(base + lay.prev_off);
+      const uint16_t* sh_prev = prevs_of(q, base);
       double* drow = reinterpret_cast<double*>(base + lay.rows_off) + 2 * kQBase + (size_t)r * 2 * kQBase;
       const int cw = ctl_load(c, lane);
       const int n = CTL_INT(cw, n), nslabs = CTL_INT(cw, nslabs), p = CTL_INT(cw, problem);
@@ -1100,7 +1106,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     const int2* tdelta = reinterpret_cast<const int2*>(base + lay.tdelta_off);
     const float2* sh_src = reinterpret_cast<const float2*>(base + lay.src_off);
     const double2* sh_src64 = reinterpret_cast<const double2*>(base + lay.src_off);
-    const uint16_t* sh_prev = reinterpret_cast<const uint16_t*>(base + lay.prev_off);
+    const uint16_t* sh_prev = prevs_of(q, base);
     double* rows = reinterpret_cast<double*>(base + lay.rows_off);
     const int cw = ctl_load(c, lane);
     const int n = CTL_INT(cw, n), nslabs = CTL_INT(cw, nslabs);
@@ -1309,7 +1315,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
     lay.tdelta_off = (uint32_t)off; if (f64 && !incr) off += (size_t)padded * sizeof(float2);
     lay.src_off = 0xffffffffu;
     if (src_in_lds && !incr) { lay.src_off = (uint32_t)off; off += up((size_t)max_src_n * (f64 ? sizeof(double2) : sizeof(float2))); }
-    lay.prev_off = (uint32_t)off; off += up((size_t)max_src_n * sizeof(uint16_t));
+    lay.prev_off = (uint32_t)off; if (!incr) off += up((size_t)max_src_n * sizeof(uint16_t));      // running sums: in sc.margins
     lay.margin_off = (uint32_t)off; if (certify && !f64 && !incr) off += up((size_t)max_src_n * sizeof(uint16_t));      // float64-exact mode, running sums: sc.margins
     lay.rows_off = (uint32_t)off; off += sizeof(double) * (size_t)(incr ? kQIncrDoubles : (rows_cap * RS > 16 ? rows_cap * RS : 16));
     return up(off);
@@ -1358,7 +1364,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   lay.cls = cls; lay.order = sc.order;
   lay.margins = sc.margins;
   lay.margin_stride = (uint32_t)((max_src_n + 63) & ~(int64_t)63);
-  if ((f64 || incr) && certify && (!sc.margins || (size_t)(S < cus ? S : cus) * 16 * lay.margin_stride * (incr ? 2 : 1) > sc.margin_cap)) return hipErrorInvalidValue;
+  if ((f64 || incr) && certify && (!sc.margins || (size_t)(S < cus ? S : cus) * 16 * lay.margin_stride * (incr ? 3 : 1) > sc.margin_cap)) return hipErrorInvalidValue;
   lay.debug = getenv("LSLAM_DEBUG") ? 1 : 0;
   const size_t smem = lay.ctl_bytes + (size_t)Q * slot;
   if (smem > kLdsPerCu) return hipErrorInvalidValue;
