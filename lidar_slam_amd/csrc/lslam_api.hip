@@ -202,7 +202,7 @@ struct PruneHolder {
       cap_order = (size_t)S;
     }
     // the task-queue kernel's margins (float64-exact mode, running sums): at most 16 slots of kPruneMaxPoints sources per workgroup, one workgroup per CU
-    if (!sc.margins) {
+    if (!sc.margins && (max_src_n >= kQueueCertifyPoints || max_tgt_n >= kQueueCertifyPoints || getenv("LSLAM_ICP_QUEUE_CERTIFY"))) {
       int cus = 0;
       LSLAM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
       if (cus <= 0) cus = 256;
