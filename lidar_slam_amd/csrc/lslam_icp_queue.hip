@@ -30,6 +30,18 @@
 // float64-exact mode the near-tie window inside the margin — and the source keeps its match.  The sources of a task whose margin
 // ran out are gathered, 64 at a time, and searched as before.  Exactness is untouched: a source is skipped only on a proof.
 //
+// RUNNING SUMS (template parameter INCR: wherever certificates are on and the normalised error's box is not asked for).  With most matches
+// kept, what an iteration still did for every pair was the moment pass — but the transform enters Σp, Σpqᵀ and Σ‖p − q‖² only through products
+// with sums over the ORIGINAL sources and the matched targets, and those change only where a match changes (formulas at `finish`).  The first
+// iteration takes them over all pairs (base_task), later searches add new − old for the lanes whose match changed, the finisher evaluates the
+// formulas.  Σ‖p − q‖² cancels five to eight digits, so the sums are double-doubles (DD) and its 25 products are formed exactly.  Certificates
+// become EXPIRIES (a float per source in a scratch buffer: the value of the slot's accumulated step bound at which the margin runs out), the
+// matches live beside them, per block of Gb slabs the earliest expiry is kept in LDS — a block none of whose certificates runs out is not
+// visited, and an iteration in which none runs out anywhere is taken by the finishing wave alone (new T from the same sums, error, stop
+// rules).  A slot is then the chunk records + 2 KB: four 4096-point problems per CU, in float64-exact mode as well (the float64 points are
+// read from the sorted copies in memory where a match changes).  Which build iterates a problem depends on the problem's own size
+// (launch_icp_pruned files the problems of a mixed batch by class), so every bit of its result is independent of the batch.
+//
 // LDS record of a chunk: its 16 targets (128 B) followed by its box (16 B) — 144 B.  A lane that compares its point with a
 // chunk reads eight 16-byte pairs at IMMEDIATE offsets from one address register (no per-target address arithmetic); lanes on
 // different chunks fall on the same banks only when their chunk ids agree modulo 16, and the 64 boxes of a ballot group are a
@@ -42,7 +54,7 @@
 // that unit below 2²⁹ of them, so f64(t32) + ldexp(count, e − 54) IS the float64 target, bit for bit (8 bytes per target
 // instead of 16).  The moments of every iteration come from LDS; round 3's kernels re-read the float64 clouds from HBM in every
 // iteration (33 GB per C4 launch against 0.8 GB compulsory).  Near ties are rare and decided on the float64 targets read from the
-// sorted copy in memory.
+// sorted copy in memory.  (That is the build WITHOUT running sums — LiDAR-sized problems; with them no float64 point is kept on chip.)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stddef.h>
