@@ -37,7 +37,9 @@ extern "C" {
 #define LSLAM_ERR_BAD_ARG      (-1)  /* NULL pointer, bad dim, negative size, non-monotone offsets ...      */
 #define LSLAM_ERR_EMPTY_TARGET (-2)  /* reference: IndexError from pc2[correspondences] (icp.py:118)        */
 #define LSLAM_ERR_NONFINITE    (-3)  /* reference: ValueError "'x' must be finite" from KDTree (icp.py:161) */
-#define LSLAM_ERR_HIP          (-4)  /* any HIP runtime failure, including "no device"                      */
+#define LSLAM_ERR_HIP          (-4)  /* any HIP runtime failure, including "no device"; also: the pruned batch
+                                       * kernel's waves gave up waiting for work (a can't-happen guard: no result
+                                       * is returned rather than an incomplete one)                              */
 
 #define LSLAM_ABI_VERSION 1
 

@@ -178,6 +178,7 @@ struct PruneHolder {
       release();
       device = dev;
       LSLAM_HIP_TRY(hipMalloc(&sc.queue, 256));
+      LSLAM_HIP_TRY(hipMemset(sc.queue, 0, 256));
       LSLAM_HIP_TRY(hipMalloc(&sc.src_sorted, sizeof(float2) * need_src));
       LSLAM_HIP_TRY(hipMalloc(&sc.src_index, sizeof(uint16_t) * need_src));
       LSLAM_HIP_TRY(hipMalloc(&sc.tgt_sorted, sizeof(float2) * need_tgt));
@@ -523,7 +524,15 @@ static int icp_batch_host(const PT* src, const int64_t* src_off, const PT* tgt, 
   LSLAM_HIP_TRY(hipMemcpyAsync(out_err, d_err, sizeof(double) * S, hipMemcpyDeviceToHost, st));
   LSLAM_HIP_TRY(hipMemcpyAsync(out_iters, d_it, sizeof(int32_t) * S, hipMemcpyDeviceToHost, st));
   if (out_corr) LSLAM_HIP_TRY(hipMemcpyAsync(out_corr, d_corr, b_corr, hipMemcpyDeviceToHost, st));
+  // the task-queue kernel's can't-happen guard (waves that found no task for 4 s and left): results would be missing — say so
+  unsigned gave_up = 0;
+  unsigned* const qflags = prune_holder().sc.queue;
+  if (qflags) LSLAM_HIP_TRY(hipMemcpyAsync(&gave_up, qflags + 50, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   LSLAM_HIP_TRY(hipStreamSynchronize(st));
+  if (gave_up) {
+    (void)hipMemset(qflags + 50, 0, sizeof(unsigned));
+    return fail(LSLAM_ERR_HIP, "the pruned batch kernel gave up waiting for work (%u waves): results are incomplete", gave_up);
+  }
   return LSLAM_OK;
 }
 }  // extern "C++"

@@ -244,6 +244,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   const bool box = (args.flags & kFlagNormalize) != 0;
   const int RS = box ? 13 : 9;                                 // doubles per row: Σp(2) Σq(2) Σpqᵀ(4) Σ‖p−q‖² [+ lo(2) hi(2)]
   int* sh_fail = reinterpret_cast<int*>(smem + (size_t)Q * kQCtlBytes);
+  int* sh_beat = sh_fail + 1;                                  // bumped by a wave that takes iterations on its own: the idle ones see that the workgroup is alive
   uint32_t* tickets = reinterpret_cast<uint32_t*>(smem + (size_t)Q * kQCtlBytes + 64);       // [16]
   int32_t* states = reinterpret_cast<int32_t*>(smem + (size_t)Q * kQCtlBytes + 128);         // [16]
   auto open_slot = [&](int q, int ntasks) { __hip_atomic_store(&tickets[q], (unsigned)ntasks << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
@@ -263,7 +264,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     states[tid] = tid < Q ? 2 : 0;
     if (tid < Q) { QueueCtl* c = ctl_of(tid); c->done_tasks = 0; c->problem = -1; }
   }
-  if (tid == 0) *sh_fail = 0;
+  if (tid == 0) { *sh_fail = 0; *sh_beat = 0; }
   __syncthreads();                                             // the only barrier of the kernel
 
   // An iteration of a problem is two rounds of tasks.  SEARCH tasks (phase 0) cover Ga consecutive slabs each and leave the
@@ -636,7 +637,10 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       if (INCR && lay.debug && lane == 0 && stepR < INFINITY) {
         if (rerun) { atomicAdd(&lay.queue[3], 1u); atomicAdd(&lay.queue[32], (unsigned)__builtin_popcount(rerun)); } else atomicAdd(&lay.queue[33], 1u);
       }
-      if (INCR && rerun == 0u) continue;
+      if (INCR && rerun == 0u) {
+        if (lane == 0) __hip_atomic_fetch_add(sh_beat, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        continue;
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) open_slot(q, nslabs > 0 ? (nslabs + G - 1) / G : 1);                                    // next iteration
       return;
@@ -1236,6 +1240,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   QUEUE_MARK(3);
   int pref = wave % Q;
   long long idle_since = -1;
+  int last_beat = 0;
   for (;;) {
     // every slot's ticket with one load (lane q: slot q); the open slots as a ballot; the first one from `pref` on
     const unsigned w = __hip_atomic_load(&tickets[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1260,9 +1265,10 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     if (!__any(lane < Q && st_ != 0)) break;
     if (lds_load_i32(sh_fail)) break;
     const long long now = (long long)wall_clock64();
-    if (idle_since < 0) idle_since = now;
-    else if (now - idle_since > kQTimeoutTicks) {             // can't happen on a healthy device: leave so that the grid drains
-      if (lane == 0) { __hip_atomic_store(sh_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicAdd(&lay.queue[1], 1u); }
+    const int beat = lds_load_i32(sh_beat);
+    if (idle_since < 0 || beat != last_beat) { idle_since = now; last_beat = beat; }
+    else if (now - idle_since > lay.timeout_ticks) {             // can't happen on a healthy device: leave so that the grid drains
+      if (lane == 0) { __hip_atomic_store(sh_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicAdd(&lay.queue[1], 1u); atomicAdd(&lay.queue[50], 1u); }
       break;
     }
     __builtin_amdgcn_s_sleep(QEXP_SLEEP);
@@ -1373,6 +1379,8 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   lay.e0_frac = 1.f;                                         // C4: 2.81 -> 2.58 ms (float64-exact 3.25 -> 3.08); flat from 1 to 3
   if (const char* e = getenv("LSLAM_ICP_QUEUE_E0")) lay.e0_frac = (float)atof(e);
   lay.queue = sc.queue;
+  lay.timeout_ticks = kQTimeoutTicks;
+  if (const char* e = getenv("LSLAM_ICP_QUEUE_TIMEOUT_US")) lay.timeout_ticks = (long long)(atof(e) * 100.0);      // (tests of the give-up path)
   lay.cls = cls; lay.order = sc.order;
   lay.margins = sc.margins;
   lay.margin_stride = (uint32_t)((max_src_n + 63) & ~(int64_t)63);

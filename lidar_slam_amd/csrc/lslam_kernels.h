@@ -77,7 +77,7 @@ struct PruneScratch {                      // Morton-sorted copies: problem k ow
   double2* src64_sorted; double2* tgt64_sorted;
   uint16_t* margins; size_t margin_cap;    // float64-exact mode, task-queue kernel: a row of margins (halves) per LDS slot of every workgroup; capacity in entries
   int32_t* order;                          // problems by class, written by icp_sort_kernel: those below 2048 points per cloud from the front, the others from the back (queue[48], queue[49] count them)
-  unsigned* queue;                         // 256 bytes: [0] next problem of the task-queue kernel, [1] waves that gave up waiting, [2] tie passes, [4…] profile
+  unsigned* queue;                         // 256 bytes: [0] next problem of the task-queue kernel, [1] waves that gave up waiting, [2] tie passes, [4…] profile, [48] [49] problems per class, [50] waves that gave up since the host last looked (never reset by a launch)
 };
 // lslam_icp_queue.hip: byte offsets inside one LDS slot (the target tile is at 0), slots per workgroup, slabs per task
 struct QueueLayout {
@@ -90,6 +90,7 @@ struct QueueLayout {
   int32_t Q, G, rows_cap;                                          // G = 0: task size chosen per problem and iteration
   unsigned* queue;
   int32_t debug;
+  long long timeout_ticks;                                         // idle waves leave after this many 100 MHz ticks without any sign of life in their workgroup (4 s)
   int32_t cls;                                                     // −1: problems 0 … S−1; 0 / 1: the problems of that class (PruneScratch::order)
   const int32_t* order;
   uint16_t* margins; uint32_t margin_stride;                       // float64-exact mode: slot q of workgroup b keeps its margins at margins[(b·Q + q)·margin_stride …]

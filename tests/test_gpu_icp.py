@@ -1215,6 +1215,30 @@ def test_task_queue_kernel_gives_the_all_pairs_answers(icp, prec, knobs, monkeyp
         np.testing.assert_allclose(b.error[ok], a.error[ok], rtol=1e-9, atol=1e-12)
 
 
+def test_task_queue_kernel_says_so_when_waves_give_up(icp, monkeypatch):
+    """the can't-happen guard of the task-queue kernel: waves that see no sign of life in their workgroup for 4 s leave, so that the grid
+    always drains.  With the bound set to (almost) nothing every idle poll gives up: the launch ends, results are missing, and the host
+    entry point must return an error instead of them; the next ordinary call works again."""
+    from lidar_slam_amd._lib import LslamError
+    from lidar_slam_amd.batch import icp_batch
+    rng = np.random.default_rng(3)
+    srcs, tgts = [], []
+    for _ in range(600):
+        s, t = _random_problem(rng, 2, 1081, 1081, spread=8.0)
+        srcs.append(s.astype(np.float32)); tgts.append(t.astype(np.float32))
+    from lidar_slam_amd.batch import pack_clouds
+    fs, so = pack_clouds(srcs, dtype=np.float32); ft, to = pack_clouds(tgts, dtype=np.float32)
+    I = np.tile(np.eye(4), (len(srcs), 1, 1))
+    monkeypatch.setenv("LSLAM_ICP_QUEUE_TIMEOUT_US", "0.01")
+    with pytest.raises(LslamError, match="gave up"):
+        icp_batch(fs, so, ft, to, I, prune=True, epsilon=1e-3)
+    monkeypatch.delenv("LSLAM_ICP_QUEUE_TIMEOUT_US")
+    good = icp_batch(fs, so, ft, to, I, prune=True, epsilon=1e-3)
+    ref = icp_batch(fs, so, ft, to, I, prune=False, epsilon=1e-3)
+    np.testing.assert_array_equal(good.iterations, ref.iterations)
+    np.testing.assert_allclose(good.T, ref.T, atol=1e-9)
+
+
 @pytest.mark.parametrize("incr", ["1", "0"])
 def test_task_queue_certificates_on_clouds_made_of_near_ties(icp, prec, incr, monkeypatch):
     """certificates and running sums forced on for clouds in which EVERY source has four candidates the float32 search cannot tell apart
