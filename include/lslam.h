@@ -148,7 +148,9 @@ int lslam_icp_batch_dev(const float *d_src, const int64_t *d_src_off,
  * reference to float64 summation order.  Same arguments otherwise; same search strategies.
  * lslam_icp_batch_f64: host float64 clouds (uploaded once, rounded to float32 on the device).
  * lslam_icp_batch_dev64: device pointers to BOTH copies, laid out alike (d_src64 / d_tgt64 may both be NULL:
- * then it is lslam_icp_batch_dev). */
+ * then it is lslam_icp_batch_dev).  The float32 copy must be the float64 one rounded to nearest, coordinate by
+ * coordinate — the near-tie bound is the bound of that rounding, and the kernels search with whichever of the
+ * two is at hand. */
 int lslam_icp_batch_f64(const double *src, const int64_t *src_off,
                         const double *tgt, const int64_t *tgt_off,
                         int dim, const double *init_T, int32_t S,

@@ -83,7 +83,7 @@ __device__ inline void bitonic_sort(unsigned* keys, int len) {
 constexpr int kSortCellMax = 48;
 template <int kSortThreads>       // 256 lanes for LiDAR-sized clouds (seven workgroups per CU), 512 from 2048 points per cloud (C4: 0.70 -> 0.50 ms)
 __global__ void __launch_bounds__(kSortThreads)
-icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, int curve, int cap, int cur_words) {
+icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, int curve, int cap, int cur_words, int skip64) {
   // LDS sized by the launch for the batch's largest cloud (cap points, cur_words counters ≥ cells + 1 and ≥ len_pow2 keys):
   // LiDAR-sized batches keep seven workgroups per CU, 4096-point clouds two
   extern __shared__ __align__(16) unsigned char smem[];
@@ -101,6 +101,9 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, 
   const int n = (int)(a.src_off[pair + 1] - s0), m = (int)(a.tgt_off[pair + 1] - t0);
   const float2* src = reinterpret_cast<const float2*>(a.src) + s0;
   const float2* tgt = reinterpret_cast<const float2*>(a.tgt) + t0;
+  // float64-exact mode: the sorted float64 copies — not for problems the running-sums build of the queue kernel iterates (skip64 = 1: those
+  // with a cloud of kQueueCertifyPoints or more, 2: all): it reads the few float64 points it needs through the index maps
+  const bool copy64 = !(skip64 == 2 || (skip64 == 1 && (n >= kQueueCertifyPoints || m >= kQueueCertifyPoints)));
   // the sorted copies live in pair-local slots of the scratch (slot = pair · stride): the caller's offsets may
   // start anywhere in a larger packed buffer, the scratch is sized for this batch only
   const int64_t ss = (int64_t)pair * sc.src_stride, ts = (int64_t)pair * sc.tgt_stride;
@@ -233,7 +236,7 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, 
     const unsigned o = ord[j];
     sc.tgt_sorted[ts + j] = pts[o];
     sc.tgt_index[ts + j] = (uint16_t)o;
-    if (a.tgt64) sc.tgt64_sorted[ts + j] = reinterpret_cast<const double2*>(a.tgt64)[t0 + o];
+    if (a.tgt64 && copy64) sc.tgt64_sorted[ts + j] = reinterpret_cast<const double2*>(a.tgt64)[t0 + o];
   }
   __syncthreads();
 
@@ -252,7 +255,7 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, 
     const unsigned o = ord[i];
     sc.src_sorted[ss + i] = pts[o];
     sc.src_index[ss + i] = (uint16_t)o;
-    if (a.src64) sc.src64_sorted[ss + i] = reinterpret_cast<const double2*>(a.src64)[s0 + o];
+    if (a.src64 && copy64) sc.src64_sorted[ss + i] = reinterpret_cast<const double2*>(a.src64)[s0 + o];
   }
   // the problem's class (launch_icp_pruned): which kernel iterates a problem depends on its own size, not on the batch it came in
   if (sc.order && tid == 0) {
@@ -806,7 +809,19 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   const bool split = sc.order && sc.queue && big >= kQueueCertifyPoints && !getenv("LSLAM_ICP_QUEUE_CERTIFY");
   PruneScratch scs = sc;
   if (!split) scs.order = nullptr;
-  else {
+  // which problems the queue kernel will iterate on running sums (launch_icp_queue decides the same way): they need no sorted float64 copies
+  int skip64 = 0;
+  {
+    bool queue_on = sc.queue != nullptr;
+    if (const char* env = getenv("LSLAM_ICP_PRUNE_QUEUE")) queue_on = queue_on && atoi(env) != 0;
+    bool incr_ok = queue_on && a.src64 && !(a.flags & kFlagNormalize);
+    if (const char* env = getenv("LSLAM_ICP_QUEUE_INCR")) incr_ok = incr_ok && atoi(env) != 0;
+    if (incr_ok) {
+      if (const char* env = getenv("LSLAM_ICP_QUEUE_CERTIFY")) skip64 = atoi(env) != 0 ? 2 : 0;
+      else skip64 = big >= kQueueCertifyPoints ? 1 : 0;
+    }
+  }
+  if (split) {
     const hipError_t ee = hipMemsetAsync(sc.queue + 48, 0, 2 * sizeof(unsigned), stream);
     if (ee != hipSuccess) return ee;
   }
@@ -814,7 +829,7 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
     auto sort_s = [&](auto kernel, int threads) -> hipError_t {
       hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
       if (ee != hipSuccess) return ee;
-      hipLaunchKernelGGL(kernel, dim3(S), dim3(threads), sort_lds, stream, a, scs, len, keep, curve, cap, cur_words);
+      hipLaunchKernelGGL(kernel, dim3(S), dim3(threads), sort_lds, stream, a, scs, len, keep, curve, cap, cur_words, skip64);
       return hipSuccess;
     };
     const hipError_t ee = big >= 2048 ? sort_s(icp_sort_kernel<512>, 512) : sort_s(icp_sort_kernel<256>, 256);

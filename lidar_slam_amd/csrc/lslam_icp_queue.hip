@@ -99,6 +99,7 @@ struct QueueCtl {                                      // one per slot, in LDS; 
   uint32_t rerun;                                      // … bit b = block b (Gb slabs) holds a source whose certificate may have run out: its task must look
   float moved;                                         // … Σ of the steps' displacement bounds so far (rounded up): a source searched at `moved` = a with margin g is certified while a + g > moved
   int32_t Gb;                                          // … slabs per block = per task after the first iteration
+  uint32_t rounds;                                     // (LSLAM_DEBUG) rounds this problem has opened after the first
 };
 static_assert(sizeof(QueueCtl) <= kQCtlBytes, "control block");
 #define QCTL_DWORD(field) (int)(offsetof(QueueCtl, field) / 4)
@@ -418,8 +419,8 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
           const int i = i0 + u * kWave + lane;
           sv[u] = make_float2(0.f, 0.f);
           if (i < n) {
-            if constexpr (F64) { const double2 pd = load_source64(src_lds, sh_src64, sc.src64_sorted + ss, i); sv[u] = make_float2((float)pd.x, (float)pd.y); }
-            else sv[u] = load_source(src_lds, sh_src, sc.src_sorted + ss, i);
+            if constexpr (F64 && !INCR) { const double2 pd = load_source64(src_lds, sh_src64, sc.src64_sorted + ss, i); sv[u] = make_float2((float)pd.x, (float)pd.y); }
+            else sv[u] = load_source(src_lds, sh_src, sc.src_sorted + ss, i);      // (running sums: the float32 clouds ARE the roundings of the float64 ones — lslam.h)
           }
         }
 #pragma unroll
@@ -447,7 +448,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       c->stop = st0; c->err = 0.0;
       c->problem = p; c->n = n; c->m = m; c->nchunks = nchunks; c->nslabs = nslabs;
       c->G = G; c->phase = 0;
-      c->done_tasks = 0; c->dirty = 0u; c->rerun = 0xffffffffu; c->moved = 0.f; c->Gb = INCR ? later_group(nslabs) : 0;
+      c->done_tasks = 0; c->dirty = 0u; c->rerun = 0xffffffffu; c->moved = 0.f; c->Gb = INCR ? later_group(nslabs) : 0; c->rounds = 0u;
       c->Rt = sqrtf(tmax) * 1.0001f;
       c->Rs = sqrtf(smax) * 1.0001f;
       c->stepR = INFINITY; c->stepT = INFINITY;               // no earlier transform: nothing is certified in the first iteration
@@ -632,10 +633,12 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         // the next searches extend their reach by E ≈ kQExtend × this step (the steps of a converging run shrink geometrically:
         // margins of E / 2 then outlast what is still to come); nothing while the steps exceed what E may cost
         const float moved = stepR * c->Rs + stepT, cap = c->ecap;
-        c->extend = CERT ? (kQExtend * moved <= cap ? kQExtend * moved : (moved <= cap ? cap : 0.f)) : 0.f;
+        // … and never less than a share of the cap: a source searched late in the run, when the steps are tiny, would otherwise get a margin
+        // of E/2 below the rounding slack — none — and be searched again in every iteration left
+        c->extend = CERT ? (moved <= cap ? fminf(fmaxf(kQExtend * moved, lay.efloor_frac * cap), cap) : 0.f) : 0.f;
       }
       if (INCR && lay.debug && lane == 0 && stepR < INFINITY) {
-        if (rerun) { atomicAdd(&lay.queue[3], 1u); atomicAdd(&lay.queue[32], (unsigned)__builtin_popcount(rerun)); } else atomicAdd(&lay.queue[33], 1u);
+        if (rerun) { atomicAdd(&lay.queue[3], 1u); atomicAdd(&lay.queue[32], (unsigned)__builtin_popcount(rerun)); c->rounds += 1u; } else atomicAdd(&lay.queue[33], 1u);
       }
       if (INCR && rerun == 0u) {
         if (lane == 0) __hip_atomic_fetch_add(sh_beat, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -651,6 +654,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     const double tn = tn_out, err = err_out;
     const StopState st = st_out;
     const int p = lds_load_i32(&c->problem);
+    if (INCR && lay.debug && lane == 0) { const unsigned r_ = c->rounds; atomicAdd(&lay.queue[40 + (r_ < 8u ? 0 : (r_ < 16u ? 1 : (r_ < 32u ? 2 : 3)))], 1u); }
     if (lane < 16) args.out_T[(int64_t)16 * p + lane] = tn;
     if (lane == 0) { args.out_err[p] = err; args.out_iters[p] = st.executed; }
     if (args.out_corr) {                                       // correspondences of the LAST iteration (icp.py:117, 187-189), caller's numbering
@@ -689,6 +693,11 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     }
     const float2* __restrict__ gsrc = sc.src_sorted + (int64_t)p * sc.src_stride;
     const double2* __restrict__ gsrc64 = F64 ? sc.src64_sorted + (int64_t)p * sc.src_stride : nullptr;
+    // running sums in float64-exact mode: no sorted float64 copies exist (icp_sort_kernel skips them) — the few float64 points that are needed
+    // (near ties, changed matches, the first iteration's sums) are read from the caller's arrays through the sorted order's index maps
+    const double2* __restrict__ src64o = F64 ? reinterpret_cast<const double2*>(args.src64) + args.src_off[p] : nullptr;
+    const double2* __restrict__ tgt64o = F64 ? reinterpret_cast<const double2*>(args.tgt64) + args.tgt_off[p] : nullptr;
+    const uint16_t* __restrict__ sidx = sc.src_index + (int64_t)p * sc.src_stride;
     double T[2][4];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -724,7 +733,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       float ax = 0.f, ay = 0.f;
       if (owns) {
         float2 v;
-        if constexpr (F64) { const double2 pd = load_source64(src_lds, sh_src64, gsrc64, i); v = make_float2((float)pd.x, (float)pd.y); }
+        if constexpr (F64 && !INCR) { const double2 pd = load_source64(src_lds, sh_src64, gsrc64, i); v = make_float2((float)pd.x, (float)pd.y); }
         else v = load_source(src_lds, sh_src, gsrc, i);
         ax = (float)(T[0][0] * (double)v.x + T[0][1] * (double)v.y + T[0][3]);      // icp.py:116
         ay = (float)(T[1][0] * (double)v.x + T[1][1] * (double)v.y + T[1][3]);
@@ -825,7 +834,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
           const float lim = far ? INFINITY : (near ? (CERT ? fmaxf(near_lim(bd, nt), dseed * dseed * 1.000002f) : near_lim(bd, nt)) : -INFINITY);
           double adx = 0.0, ady = 0.0;
           if (near || far) {
-            const double2 pd = load_source64(src_lds, sh_src64, gsrc64, i);
+            const double2 pd = INCR ? src64o[sidx[i]] : load_source64(src_lds, sh_src64, gsrc64, i);
             adx = T[0][0] * pd.x + T[0][1] * pd.y + T[0][3];
             ady = T[1][0] * pd.x + T[1][1] * pd.y + T[1][3];
           }
@@ -859,7 +868,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
               const float2 qv = target_at(j);
               if (dist2(ax, ay, qv.x, qv.y) <= lim) {          // rare: a candidate of this lane
                 const int o = tidx[j];
-                const double2 td = gtgt64[j];
+                const double2 td = INCR ? tgt64o[o] : gtgt64[j];
                 const double dx = adx - td.x, dy = ady - td.y;
                 const double e = dx * dx + dy * dy;
                 if (e < bv || (e == bv && o < bo)) { bv2 = bv; bv = e; bo = o; bp = j; }
@@ -912,7 +921,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
           double x = 0.0, y = 0.0, qnx = 0.0, qny = 0.0, qox = 0.0, qoy = 0.0;
           if (changed) {
             if constexpr (F64) {
-              const double2 sp = gsrc64[i], tn_ = gtgt64[pos], to_ = gtgt64[pv];
+              const double2 sp = src64o[sidx[i]], tn_ = tgt64o[tidx[pos]], to_ = tgt64o[tidx[pv]];
               x = sp.x; y = sp.y; qnx = tn_.x; qny = tn_.y; qox = to_.x; qoy = to_.y;
             } else {
               const float2 v = gsrc[i], tn_ = target_at(pos), to_ = target_at(pv);
@@ -1059,56 +1068,72 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       const int cw = ctl_load(c, lane);
       const int n = CTL_INT(cw, n), nslabs = CTL_INT(cw, nslabs), p = CTL_INT(cw, problem);
       const float2* __restrict__ gsrc = sc.src_sorted + (int64_t)p * sc.src_stride;
-      const double2* __restrict__ gsrc64 = F64 ? sc.src64_sorted + (int64_t)p * sc.src_stride : nullptr;
-      const double2* __restrict__ gtgt64 = F64 ? sc.tgt64_sorted + (int64_t)p * sc.tgt_stride : nullptr;
+      const double2* __restrict__ src64o = F64 ? reinterpret_cast<const double2*>(args.src64) + args.src_off[p] : nullptr;
+      const double2* __restrict__ tgt64o = F64 ? reinterpret_cast<const double2*>(args.tgt64) + args.tgt_off[p] : nullptr;
+      const uint16_t* __restrict__ sidx = sc.src_index + (int64_t)p * sc.src_stride;
+      const uint16_t* __restrict__ tidx = sc.tgt_index + (int64_t)p * sc.tgt_stride;
       const int slab_lo = r * base_slabs(nslabs), slab_hi = min(slab_lo + base_slabs(nslabs), nslabs);
-      // three passes of at most five sums each (twelve double-double accumulators at once do not fit the 128 registers of a 16-wave workgroup)
-      auto source_at = [&](int i, double& x, double& y) {
-        if constexpr (F64) { const double2 sp = gsrc64[i]; x = sp.x; y = sp.y; }
-        else { const float2 v = gsrc[i]; x = (double)v.x; y = (double)v.y; }
-      };
-      auto match_at = [&](int i, double& qx, double& qy) {
-        const int ps = sh_prev[i];
-        if constexpr (F64) { const double2 tq = gtgt64[ps]; qx = tq.x; qy = tq.y; }
-        else { const float2 qv = *reinterpret_cast<const float2*>(base + rec_off(ps)); qx = (double)qv.x; qy = (double)qv.y; }
-      };
+      // two passes (twelve double-double accumulators at once do not fit the 128 registers of a 16-wave workgroup), four slabs at a time:
+      // the index maps, then the points they lead to, are in flight together — one slab at a time, a task waited for 80 dependent loads
+      constexpr int BS = 2;
       auto leave = [&](int k0, DD v) {                       // sum k0 of the row, from lane 63
         v = wave_sum_dd_last(v);
         if (lane == 63) { drow[2 * k0] = v.hi; drow[2 * k0 + 1] = v.lo; }
         __builtin_amdgcn_sched_barrier(0);
       };
+      auto sources_of = [&](int s0, bool (&ok)[BS], double (&x)[BS], double (&y)[BS]) {
+        if constexpr (F64) {
+          int si[BS];
+#pragma unroll
+          for (int u = 0; u < BS; ++u) { const int i = (s0 + u) * kWave + lane; ok[u] = s0 + u < slab_hi && i < n; si[u] = ok[u] ? (int)sidx[i] : 0; }
+#pragma unroll
+          for (int u = 0; u < BS; ++u) { const double2 sp = ok[u] ? src64o[si[u]] : make_double2(0.0, 0.0); x[u] = sp.x; y[u] = sp.y; }
+        } else {
+#pragma unroll
+          for (int u = 0; u < BS; ++u) {
+            const int i = (s0 + u) * kWave + lane; ok[u] = s0 + u < slab_hi && i < n;
+            const float2 v = ok[u] ? gsrc[i] : make_float2(0.f, 0.f); x[u] = (double)v.x; y[u] = (double)v.y;
+          }
+        }
+      };
       {
         DD a0{0.0, 0.0}, a1{0.0, 0.0}, a2{0.0, 0.0}, a3{0.0, 0.0}, a4{0.0, 0.0};
-        for (int slab = slab_lo; slab < slab_hi; ++slab) {
-          const int i = slab * kWave + lane;
-          if (i < n) {
-            double x, y; source_at(i, x, y);
-            dd_acc(a0, x); dd_acc(a1, y); dd_acc_prod(a2, x, x); dd_acc_prod(a3, x, y); dd_acc_prod(a4, y, y);
-          }
+        for (int s0 = slab_lo; s0 < slab_hi; s0 += BS) {
+          bool ok[BS]; double x[BS], y[BS];
+          sources_of(s0, ok, x, y);
+#pragma unroll
+          for (int u = 0; u < BS; ++u)
+            if (ok[u]) { dd_acc(a0, x[u]); dd_acc(a1, y[u]); dd_acc_prod(a2, x[u], x[u]); dd_acc_prod(a3, x[u], y[u]); dd_acc_prod(a4, y[u], y[u]); }
         }
         leave(0, a0); leave(1, a1); leave(2, a2); leave(3, a3); leave(4, a4);
       }
       {
-        DD a5{0.0, 0.0}, a6{0.0, 0.0}, a11{0.0, 0.0};
-        for (int slab = slab_lo; slab < slab_hi; ++slab) {
-          const int i = slab * kWave + lane;
-          if (i < n) {
-            double qx, qy; match_at(i, qx, qy);
-            dd_acc(a5, qx); dd_acc(a6, qy); dd_acc_prod(a11, qx, qx); dd_acc_prod(a11, qy, qy);
+        DD a5{0.0, 0.0}, a6{0.0, 0.0}, a7{0.0, 0.0}, a8{0.0, 0.0}, a9{0.0, 0.0}, a10{0.0, 0.0}, a11{0.0, 0.0};
+        for (int s0 = slab_lo; s0 < slab_hi; s0 += BS) {
+          bool ok[BS]; double x[BS], y[BS], qx[BS], qy[BS];
+          int ps[BS];
+#pragma unroll
+          for (int u = 0; u < BS; ++u) { const int i = (s0 + u) * kWave + lane; ps[u] = (s0 + u < slab_hi && i < n) ? (int)sh_prev[i] : 0; }
+          sources_of(s0, ok, x, y);
+          if constexpr (F64) {
+            int ti[BS];
+#pragma unroll
+            for (int u = 0; u < BS; ++u) ti[u] = ok[u] ? (int)tidx[ps[u]] : 0;
+#pragma unroll
+            for (int u = 0; u < BS; ++u) { const double2 tq = ok[u] ? tgt64o[ti[u]] : make_double2(0.0, 0.0); qx[u] = tq.x; qy[u] = tq.y; }
+          } else {
+#pragma unroll
+            for (int u = 0; u < BS; ++u) { const float2 qv = *reinterpret_cast<const float2*>(base + rec_off(ps[u])); qx[u] = (double)qv.x; qy[u] = (double)qv.y; }
           }
+#pragma unroll
+          for (int u = 0; u < BS; ++u)
+            if (ok[u]) {
+              dd_acc(a5, qx[u]); dd_acc(a6, qy[u]);
+              dd_acc_prod(a7, x[u], qx[u]); dd_acc_prod(a8, x[u], qy[u]); dd_acc_prod(a9, y[u], qx[u]); dd_acc_prod(a10, y[u], qy[u]);
+              dd_acc_prod(a11, qx[u], qx[u]); dd_acc_prod(a11, qy[u], qy[u]);
+            }
         }
-        leave(5, a5); leave(6, a6); leave(11, a11);
-      }
-      {
-        DD a7{0.0, 0.0}, a8{0.0, 0.0}, a9{0.0, 0.0}, a10{0.0, 0.0};
-        for (int slab = slab_lo; slab < slab_hi; ++slab) {
-          const int i = slab * kWave + lane;
-          if (i < n) {
-            double x, y, qx, qy; source_at(i, x, y); match_at(i, qx, qy);
-            dd_acc_prod(a7, x, qx); dd_acc_prod(a8, x, qy); dd_acc_prod(a9, y, qx); dd_acc_prod(a10, y, qy);
-          }
-        }
-        leave(7, a7); leave(8, a8); leave(9, a9); leave(10, a10);
+        leave(5, a5); leave(6, a6); leave(7, a7); leave(8, a8); leave(9, a9); leave(10, a10); leave(11, a11);
       }
       QUEUE_MARK(1);
     }
@@ -1376,6 +1401,8 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   lay.certify = certify ? 1 : 0;
   lay.ecap_frac = 0.25f;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_ECAP")) lay.ecap_frac = (float)atof(e);
+  lay.efloor_frac = 0.25f;
+  if (const char* e = getenv("LSLAM_ICP_QUEUE_EFLOOR")) lay.efloor_frac = (float)atof(e);
   lay.e0_frac = 1.f;                                         // C4: 2.81 -> 2.58 ms (float64-exact 3.25 -> 3.08); flat from 1 to 3
   if (const char* e = getenv("LSLAM_ICP_QUEUE_E0")) lay.e0_frac = (float)atof(e);
   lay.queue = sc.queue;
@@ -1404,6 +1431,8 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
     unsigned hu[34];
     for (int k = 0; k < 32; ++k) hu[k] = reinterpret_cast<const unsigned*>(h)[k];
     hu[32] = hu_tail[0]; hu[33] = hu_tail[1];
+    { unsigned hist[4] = {0, 0, 0, 0}; (void)hipMemcpy(hist, sc.queue + 40, 16, hipMemcpyDeviceToHost);
+      if (hist[0] + hist[1] + hist[2] + hist[3]) fprintf(stderr, "[lslam] queue kernel, previous launch: problems by rounds after the first: <8: %u, <16: %u, <32: %u, more: %u\n", hist[0], hist[1], hist[2], hist[3]); }
     fprintf(stderr, "[lslam] queue kernel, previous launch: problems drawn %u, timeouts %u, tie passes %u; running sums: %u rounds of %.2f blocks after the first, %u iterations without a round\n",
             hu[0], hu[1], hu[2], hu[3], hu[3] ? (double)hu[32] / hu[3] : 0.0, hu[33]);
 #ifdef LSLAM_QUEUE_PROFILE
@@ -1420,7 +1449,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
     fprintf(stderr, "[lslam] icp_queue_kernel: %d workgroups x %d waves, %d slots of %zu B (%zu B LDS), %d rows per slot, %s\n",
             grid, W, Q, slot, smem, rows_cap, f64 ? (incr ? "float64-exact, running sums" : "float64-exact") : (incr ? "float32, running sums" : "float32"));
   }
-  hipError_t e = hipMemsetAsync(sc.queue, 0, 160, stream);      // (the counters of the debug print live in the first 136 bytes)
+  hipError_t e = hipMemsetAsync(sc.queue, 0, 176, stream);      // (the counters of the debug print live in the first 136 bytes)
   if (e != hipSuccess) return e;
   auto launch = [&](auto kernel) -> hipError_t {
     hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
