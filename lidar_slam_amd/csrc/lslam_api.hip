@@ -159,6 +159,7 @@ struct PruneHolder {
   void release() {
     if (sc.src_sorted) (void)hipFree(sc.src_sorted);
     if (sc.src_index) (void)hipFree(sc.src_index);
+    if (sc.src_rank) (void)hipFree(sc.src_rank);
     if (sc.tgt_sorted) (void)hipFree(sc.tgt_sorted);
     if (sc.tgt_index) (void)hipFree(sc.tgt_index);
     if (sc.src64_sorted) (void)hipFree(sc.src64_sorted);
@@ -166,6 +167,7 @@ struct PruneHolder {
     if (sc.queue) (void)hipFree(sc.queue);
     if (sc.margins) (void)hipFree(sc.margins);
     if (sc.order) (void)hipFree(sc.order);
+    if (sc.smax) (void)hipFree(sc.smax);
     cap_order = 0;
     sc = PruneScratch{}; cap_src = cap_tgt = cap_src64 = cap_tgt64 = 0; device = -1;
   }
@@ -181,6 +183,7 @@ struct PruneHolder {
       LSLAM_HIP_TRY(hipMemset(sc.queue, 0, 256));
       LSLAM_HIP_TRY(hipMalloc(&sc.src_sorted, sizeof(float2) * need_src));
       LSLAM_HIP_TRY(hipMalloc(&sc.src_index, sizeof(uint16_t) * need_src));
+      LSLAM_HIP_TRY(hipMalloc(&sc.src_rank, sizeof(uint16_t) * need_src));
       LSLAM_HIP_TRY(hipMalloc(&sc.tgt_sorted, sizeof(float2) * need_tgt));
       LSLAM_HIP_TRY(hipMalloc(&sc.tgt_index, sizeof(uint16_t) * need_tgt));
       cap_src = need_src; cap_tgt = need_tgt;
@@ -200,6 +203,9 @@ struct PruneHolder {
       if (sc.order) (void)hipFree(sc.order);
       sc.order = nullptr; cap_order = 0;
       LSLAM_HIP_TRY(hipMalloc(&sc.order, sizeof(int32_t) * (size_t)S));
+      if (sc.smax) (void)hipFree(sc.smax);
+      sc.smax = nullptr;
+      LSLAM_HIP_TRY(hipMalloc(&sc.smax, sizeof(float) * (size_t)S));
       cap_order = (size_t)S;
     }
     // the task-queue kernel's margins (float64-exact mode, running sums): at most 16 slots of kPruneMaxPoints sources per workgroup, one workgroup per CU

@@ -241,7 +241,12 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, 
   __syncthreads();
 
   // ---- the source: as given if compact (a rigid motion does not undo that), else placed by its initial transform into the target's grid ----
-  for (int i = tid; i < n; i += kSortThreads) pts[i] = src[i];
+  {
+    float mx = 0.f;                                            // the largest |p|² of the source, for the queue kernel's step bound and near-tie window
+    for (int i = tid; i < n; i += kSortThreads) { const float2 q = src[i]; pts[i] = q; mx = fmaxf(mx, __builtin_fmaf(q.y, q.y, q.x * q.x)); }
+    mx = wave_max_f(mx);
+    if (sc.smax && (tid & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(&sc.smax[pair]), __float_as_uint(mx));      // (≥ 0: the bit patterns order as the values)
+  }
   __syncthreads();
   bool keep_src = keep_forced >= 0 ? (keep_forced & 2) != 0 : false;
   if (keep_forced < 0) {
@@ -256,6 +261,7 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, 
     sc.src_sorted[ss + i] = pts[o];
     sc.src_index[ss + i] = (uint16_t)o;
     if (a.src64 && copy64) sc.src64_sorted[ss + i] = reinterpret_cast<const double2*>(a.src64)[s0 + o];
+    if (a.src64 && !copy64 && sc.src_rank) sc.src_rank[ss + o] = (uint16_t)i;      // (the running-sums build walks the float64 sources in the caller's order)
   }
   // the problem's class (launch_icp_pruned): which kernel iterates a problem depends on its own size, not on the batch it came in
   if (sc.order && tid == 0) {
@@ -823,6 +829,10 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   }
   if (split) {
     const hipError_t ee = hipMemsetAsync(sc.queue + 48, 0, 2 * sizeof(unsigned), stream);
+    if (ee != hipSuccess) return ee;
+  }
+  if (sc.smax) {
+    const hipError_t ee = hipMemsetAsync(sc.smax, 0, sizeof(float) * (size_t)S, stream);
     if (ee != hipSuccess) return ee;
   }
   {

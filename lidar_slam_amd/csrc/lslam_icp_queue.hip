@@ -411,7 +411,8 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     // the largest |p| of the cloud: what a change of the transform can move a source by (margins), the near-tie window (float64-exact mode)
-    if constexpr (F64 || CERT) {
+    if constexpr (INCR) smax = sc.smax[p];                    // (running sums: the sources are not on chip — icp_sort_kernel left the figure)
+    else if constexpr (F64 || CERT) {
       for (int i0 = 0; i0 < n; i0 += 8 * kWave) {              // eight loads in flight per lane
         float2 sv[8];
 #pragma unroll
@@ -1070,7 +1071,6 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
       const float2* __restrict__ gsrc = sc.src_sorted + (int64_t)p * sc.src_stride;
       const double2* __restrict__ src64o = F64 ? reinterpret_cast<const double2*>(args.src64) + args.src_off[p] : nullptr;
       const double2* __restrict__ tgt64o = F64 ? reinterpret_cast<const double2*>(args.tgt64) + args.tgt_off[p] : nullptr;
-      const uint16_t* __restrict__ sidx = sc.src_index + (int64_t)p * sc.src_stride;
       const uint16_t* __restrict__ tidx = sc.tgt_index + (int64_t)p * sc.tgt_stride;
       const int slab_lo = r * base_slabs(nslabs), slab_hi = min(slab_lo + base_slabs(nslabs), nslabs);
       // two passes (twelve double-double accumulators at once do not fit the 128 registers of a 16-wave workgroup), four slabs at a time:
@@ -1081,13 +1081,17 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         if (lane == 63) { drow[2 * k0] = v.hi; drow[2 * k0 + 1] = v.lo; }
         __builtin_amdgcn_sched_barrier(0);
       };
+      // float64-exact mode: the slabs are slabs of the CALLER's order — the float64 sources are then read as they lie in memory (and in a
+      // scan-matching batch, where source o matches target o or a neighbour, so are the targets); through the sorted order's index map every
+      // lane touched a line of its own, three times the bytes.  A sum does not care about the order; it is a fixed one either way.
+      const uint16_t* __restrict__ srank = sc.src_rank + (int64_t)p * sc.src_stride;
       auto sources_of = [&](int s0, bool (&ok)[BS], double (&x)[BS], double (&y)[BS]) {
         if constexpr (F64) {
-          int si[BS];
 #pragma unroll
-          for (int u = 0; u < BS; ++u) { const int i = (s0 + u) * kWave + lane; ok[u] = s0 + u < slab_hi && i < n; si[u] = ok[u] ? (int)sidx[i] : 0; }
-#pragma unroll
-          for (int u = 0; u < BS; ++u) { const double2 sp = ok[u] ? src64o[si[u]] : make_double2(0.0, 0.0); x[u] = sp.x; y[u] = sp.y; }
+          for (int u = 0; u < BS; ++u) {
+            const int o = (s0 + u) * kWave + lane; ok[u] = s0 + u < slab_hi && o < n;
+            const double2 sp = ok[u] ? src64o[o] : make_double2(0.0, 0.0); x[u] = sp.x; y[u] = sp.y;
+          }
         } else {
 #pragma unroll
           for (int u = 0; u < BS; ++u) {
@@ -1113,7 +1117,15 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
           bool ok[BS]; double x[BS], y[BS], qx[BS], qy[BS];
           int ps[BS];
 #pragma unroll
-          for (int u = 0; u < BS; ++u) { const int i = (s0 + u) * kWave + lane; ps[u] = (s0 + u < slab_hi && i < n) ? (int)sh_prev[i] : 0; }
+          for (int u = 0; u < BS; ++u) {
+            const int i = (s0 + u) * kWave + lane;
+            if constexpr (F64) ps[u] = (s0 + u < slab_hi && i < n) ? (int)srank[i] : 0;      // source o = i of the caller's order sits at srank[o] …
+            else ps[u] = (s0 + u < slab_hi && i < n) ? (int)sh_prev[i] : 0;
+          }
+          if constexpr (F64) {
+#pragma unroll
+            for (int u = 0; u < BS; ++u) { const int i = (s0 + u) * kWave + lane; ps[u] = (s0 + u < slab_hi && i < n) ? (int)sh_prev[ps[u]] : 0; }      // … and is matched to sorted target ps
+          }
           sources_of(s0, ok, x, y);
           if constexpr (F64) {
             int ti[BS];

@@ -69,6 +69,7 @@ constexpr double kAutoPruneLargePairEvals3D = 1e9;      // one large pair: from 
 constexpr double kAutoPruneLargePairEvals2D = 2.5e8;
 constexpr int kPruneMaxPoints = 4096;      // per cloud: both sorted clouds + boxes + indices must fit LDS
 struct PruneScratch {                      // Morton-sorted copies: problem k owns slot [k·stride, (k+1)·stride)
+  uint16_t* src_rank;                      // float64-exact running sums: position of source o in the sorted order (the inverse of src_index), same slots
   float2* src_sorted; uint16_t* src_index;
   float2* tgt_sorted; uint16_t* tgt_index;
   int64_t src_stride, tgt_stride;          // = max_src_n, max_tgt_n of the batch
@@ -76,6 +77,7 @@ struct PruneScratch {                      // Morton-sorted copies: problem k ow
   // them sequentially / from neighbouring lines instead of gathering 16 bytes per point from the caller's order
   double2* src64_sorted; double2* tgt64_sorted;
   uint16_t* margins; size_t margin_cap;    // float64-exact mode, task-queue kernel: a row of margins (halves) per LDS slot of every workgroup; capacity in entries
+  float* smax;                             // per problem: the largest |p|² of its float32 source (icp_sort_kernel has the cloud in LDS anyway; zeroed before the sort)
   int32_t* order;                          // problems by class, written by icp_sort_kernel: those below 2048 points per cloud from the front, the others from the back (queue[48], queue[49] count them)
   unsigned* queue;                         // 256 bytes: [0] next problem of the task-queue kernel, [1] waves that gave up waiting, [2] tie passes, [4…] profile, [48] [49] problems per class, [50] waves that gave up since the host last looked (never reset by a launch)
 };
