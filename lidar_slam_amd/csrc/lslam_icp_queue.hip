@@ -153,7 +153,8 @@ constexpr int kQDelta = 7;                             // … of which the last 
 constexpr int kQDeltaRows = 16;                        // tasks of a round that may leave a row of changes
 constexpr int kQBaseRows = 8;                          // tasks of the first iteration's round of sums
 constexpr int kQIncrRows = 2 * kQBase + (2 * kQDelta * kQDeltaRows > 2 * kQBase * kQBaseRows ? 2 * kQDelta * kQDeltaRows : 2 * kQBase * kQBaseRows);      // doubles: the sums, then the round's rows
-constexpr int kQIncrDoubles = kQIncrRows + kQDeltaRows / 2;      // … then one float per block: the earliest expiry among its sources
+constexpr int kQContested = 16;                        // sources per problem that may be kept on "same float32 position" instead of a margin
+constexpr int kQIncrDoubles = kQIncrRows + kQDeltaRows / 2 + (4 + 2 * kQContested + 8 * kQContested + 7) / 8;      // … then one float per block (the earliest expiry among its sources), then the contested list: count, indices, positions
 
 // A float32 source from its LDS copy or, where a slot has no room for one, from the sorted copy in memory — as two explicit
 // paths: written as one conditional expression the compiler selects between the two POINTERS and emits a flat_load (the slow
@@ -324,6 +325,18 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     if constexpr (INCR) return lay.margins + ((size_t)blockIdx.x * (size_t)Q + (size_t)q) * (size_t)lay.margin_stride * 3 + (size_t)lay.margin_stride * 2;
     else return reinterpret_cast<uint16_t*>(base + lay.prev_off);
   };
+  // A source within rounding of equidistant between two targets gets no margin, however small the steps become: its block would be searched
+  // in every iteration and its problem would never have an iteration without a round (C4: 75 of 4096 problems, a millisecond each instead
+  // of 0.4).  The search is a function of the float32 position it is given: such a source is listed (up to kQContested per problem) with
+  // that position, its expiry set to +inf, and the finisher recomputes the position with every new transform — bit-identical: the search
+  // would return what it returned; changed: the source's expiry is zeroed and its block visited.  Not in float64-exact mode when the
+  // runner-up is within 1e-4 of the near-tie window (the window moves in its last bits with T).
+  auto contested_of = [&](unsigned char* base, unsigned*& count, uint16_t*& idx, float2*& pos) {
+    unsigned char* c0 = reinterpret_cast<unsigned char*>(reinterpret_cast<double*>(base + lay.rows_off) + kQIncrRows + kQDeltaRows / 2);
+    count = reinterpret_cast<unsigned*>(c0);
+    pos = reinterpret_cast<float2*>(c0 + 8);
+    idx = reinterpret_cast<uint16_t*>(c0 + 8 + 8 * kQContested);
+  };
   auto later_group = [&](int nslabs) -> int {                // slabs per task after the first iteration: a function of the problem's size alone
     int g = lay.G > 0 ? lay.G : (nslabs > 32 ? 8 : 4);
     if (g * kQDeltaRows < nslabs) g = (nslabs + kQDeltaRows - 1) / kQDeltaRows;
@@ -408,6 +421,9 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
     if constexpr (INCR) {
       float* tmin = reinterpret_cast<float*>(reinterpret_cast<double*>(base + lay.rows_off) + kQIncrRows);
       if (lane < kQDeltaRows) tmin[lane] = INFINITY;
+      unsigned* ccount; uint16_t* cidx; float2* cpos;
+      contested_of(base, ccount, cidx, cpos);
+      if (lane == 0) *ccount = 0u;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     // the largest |p| of the cloud: what a change of the transform can move a source by (margins), the near-tie window (float64-exact mode)
@@ -625,6 +641,44 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         const bool mine = lane < nblocks && !(tmin[lane < kQDeltaRows ? lane : 0] > moved_next);
         rerun = stepR < INFINITY ? (unsigned)__ballot(mine) : 0xffffffffu;
         if (stepR < INFINITY && mine) tmin[lane] = INFINITY;   // the block's task will leave the new minimum
+        // the contested sources: does the new transform still put each of them on the float32 position it was searched at?
+        {
+          unsigned* ccount; uint16_t* cidx; float2* cpos;
+          contested_of(base, ccount, cidx, cpos);
+          const unsigned craw = lds_load_u32(ccount);
+          const unsigned cc = craw < (unsigned)kQContested ? craw : (unsigned)kQContested;
+          if (!(stepR < INFINITY)) {                           // a round over everything: whoever is still contested is listed again
+            if (lane == 0) *ccount = 0u;
+          } else if (cc) {
+            auto tl = [&](int k) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tn), k), __builtin_amdgcn_readlane(__double2loint(tn), k)); };
+            const double n00 = tl(0), n01 = tl(1), n03 = tl(3), n10 = tl(4), n11 = tl(5), n13 = tl(7);
+            const float2* __restrict__ gsrc = sc.src_sorted + (int64_t)lds_load_i32(&c->problem) * sc.src_stride;
+            int ci = 0;
+            bool gone = false;
+            float2 lp = make_float2(0.f, 0.f);
+            if (lane < (int)cc) {
+              ci = cidx[lane]; lp = cpos[lane];
+              const float2 v = gsrc[ci];
+              const float nax = (float)(n00 * (double)v.x + n01 * (double)v.y + n03);      // the expression of search_points, operation for operation
+              const float nay = (float)(n10 * (double)v.x + n11 * (double)v.y + n13);
+              gone = !(nax == lp.x && nay == lp.y);
+            }
+            const unsigned long long gm = __ballot(gone);
+            if (gm) {
+              float* expiry = expiry_of(q);
+              if (gone) expiry[ci] = 0.f;
+              unsigned extra = 0u;
+              for (unsigned long long m = gm; m; m &= m - 1ull) extra |= 1u << ((__builtin_amdgcn_readlane(ci, __builtin_ctzll(m)) / kWave) / G);
+              rerun |= extra;
+              if (lane < nblocks && ((extra >> lane) & 1u)) tmin[lane] = INFINITY;
+              const bool stays = lane < (int)cc && !gone;
+              const unsigned long long km = __ballot(stays);
+              const int to = __builtin_popcountll(km & ((1ull << lane) - 1ull));
+              if (stays) { cidx[to] = (uint16_t)ci; cpos[to] = lp; }
+              if (lane == 0) *ccount = (unsigned)__builtin_popcountll(km);
+            } else if (lane == 0 && craw != cc) *ccount = cc;
+          }
+        }
       }
       if (lane == 0) {
         c->stop = st; c->err = err; c->done_tasks = 0; c->dirty = 0u;
@@ -964,7 +1018,15 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
         }
         if (F64 && CERT && tie) mg = mg_tie;
         if constexpr (INCR) {                                    // as an expiry, rounded down
-          const float ex = mg > 0.f ? __uint_as_float(__float_as_uint(moved + mg) - 1u) : 0.f;
+          float ex = mg > 0.f ? __uint_as_float(__float_as_uint(moved + mg) - 1u) : 0.f;
+          bool listable = lay.contested && !(mg > 0.f) && !tie && bd < kQFarD2;
+          if constexpr (F64) listable = listable && sec > near_lim(bd, nt) * 1.0001f;
+          if (listable) {
+            unsigned* ccount; uint16_t* cidx; float2* cpos;
+            contested_of(base, ccount, cidx, cpos);
+            const unsigned k = atomicAdd(ccount, 1u);
+            if (k < (unsigned)kQContested) { cidx[k] = (uint16_t)i; cpos[k] = make_float2(ax, ay); ex = INFINITY; }
+          }
           expiry[i] = ex;
           emin = fminf(emin, ex);
         } else if constexpr (CERT) {                             // kept as a half, rounded toward zero (never up)
@@ -1413,6 +1475,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   lay.certify = certify ? 1 : 0;
   lay.ecap_frac = 0.25f;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_ECAP")) lay.ecap_frac = (float)atof(e);
+  lay.contested = env_int("LSLAM_ICP_QUEUE_CONTESTED", 1);
   lay.efloor_frac = 0.25f;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_EFLOOR")) lay.efloor_frac = (float)atof(e);
   lay.e0_frac = 1.f;                                         // C4: 2.81 -> 2.58 ms (float64-exact 3.25 -> 3.08); flat from 1 to 3

@@ -87,6 +87,7 @@ struct QueueLayout {
   uint32_t tdelta_off, src_off, prev_off, margin_off, rows_off;      // the chunk records (16 targets + box each) start at 0; src_off = 0xffffffff: sources read from memory
   int32_t fuse;                                                    // fused search + moment tasks from the second iteration on (certificates only)
   int32_t certify;                                                 // keep matches on a proof instead of searching every source in every iteration
+  int32_t contested;                                               // sources without a margin are kept on "same float32 position" (lslam_icp_queue.hip: contested_of)
   float efloor_frac;                                               // … and of every later iteration's at least (fraction of the cap)
   float e0_frac;                                                   // reach extension of the first iteration's searches as a fraction of that cap
   float ecap_frac;                                                 // cap of the reach extension as a fraction of the targets' mean spacing
