@@ -1177,7 +1177,8 @@ def test_release_thread_resources_and_continue(icp, prec):
 @pytest.mark.parametrize("knobs", [{}, {"LSLAM_ICP_QUEUE_CERTIFY": "1"}, {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_Q": "1", "LSLAM_ICP_QUEUE_WAVES": "3", "LSLAM_ICP_QUEUE_G": "5"},
                                    {"LSLAM_ICP_QUEUE_CERTIFY": "0", "LSLAM_ICP_QUEUE_Q": "2", "LSLAM_ICP_QUEUE_WAVES": "16"}, {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_ECAP": "4.0"},
                                    {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_LEAN_BELOW": "99"}, {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_FUSE": "0"},
-                                   {"LSLAM_ICP_QUEUE_INCR": "0"}, {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_INCR": "0", "LSLAM_ICP_QUEUE_G": "3"}])
+                                   {"LSLAM_ICP_QUEUE_INCR": "0"}, {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_INCR": "0", "LSLAM_ICP_QUEUE_G": "3"},
+                                   {"LSLAM_ICP_QUEUE_CERTIFY": "1", "LSLAM_ICP_QUEUE_CONTESTED": "0", "LSLAM_ICP_QUEUE_E0": "0", "LSLAM_ICP_QUEUE_EFLOOR": "0"}])
 def test_task_queue_kernel_gives_the_all_pairs_answers(icp, prec, knobs, monkeypatch):
     """ragged planar batch from one point to 4096 per cloud — more problems than a CU has slots, tiny and large ones mixed, duplicates, a
     lattice, motions far from the start, many forced iterations (so that most sources hold a certificate most of the time), the normalised
@@ -1241,7 +1242,8 @@ def test_task_queue_kernel_says_so_when_waves_give_up(icp, monkeypatch):
 
 @pytest.mark.parametrize("incr", ["1", "0"])
 def test_task_queue_certificates_on_clouds_made_of_near_ties(icp, prec, incr, monkeypatch):
-    """certificates and running sums forced on for clouds in which EVERY source has four candidates the float32 search cannot tell apart
+    """(also the test of the contested list: far more sources without a margin than a problem may list, exact ties that must not be listed)
+    certificates and running sums forced on for clouds in which EVERY source has four candidates the float32 search cannot tell apart
     (lattice + nanometre perturbations, as in test_float64_exact_mode_on_clouds_made_of_near_ties), a start off the solution and twenty
     forced iterations: a near tie decided on the float64 points gets its margin from the exact runner-up, an exact tie none — the
     correspondences of every iteration must still be the all-pairs sweep's (the last ones are compared, and T, error and iteration count
