@@ -849,7 +849,7 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
   if (e != hipSuccess) return e;
   // 2. iterate: the task-queue kernel (lslam_icp_queue.hip: problems in LDS slots, waves draw tasks, no barriers; from 2048 points
   // per cloud it also keeps a source's match from one iteration to the next while a proof allows it).  Round 4, same boxes: C3
-  // sequence 0.77 ms against 0.87 (float64-exact 0.91 against 0.96), C4 with 50 iterations 6.7 ms against 16.0 (float64-exact 12.5
+  // sequence 0.77 ms against 0.87 (float64-exact 0.91 against 0.96), C4 with 50 iterations 2.15 ms against 16.0 (float64-exact 2.4
   // against 17.9).  LSLAM_ICP_PRUNE_QUEUE=0 keeps one problem per workgroup (the kernel below).
   {
     bool queue = true;

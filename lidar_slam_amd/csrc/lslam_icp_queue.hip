@@ -1416,8 +1416,8 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
   QueueLayout lay{};
   // Certificates pay once a run has iterations in which little moves (C4, 50 iterations: 4 % of the source visits still search, 16.6
-  // -> 6.9 ms); a LiDAR-sized pair stops after ~6 iterations, the sources it could skip in the last of them are scattered over all
-  // slabs, and the margins cost a slot of LDS (C3: 0.72 -> 0.85 ms): from 2048 points per cloud by default.
+  // -> 6.9 ms, and 2.15 ms with the running sums they make possible); a LiDAR-sized pair stops after ~6 iterations of large steps, the sources it
+  // could skip in the last of them are scattered over all slabs (C3: 0.72 -> 0.85 ms, 1.2 ms with running sums): from 2048 points per cloud by default.
   bool certify = max_src_n >= kQueueCertifyPoints || max_tgt_n >= kQueueCertifyPoints;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_CERTIFY")) certify = atoi(e) != 0;
   if (cls >= 0 && !sc.order) return hipErrorInvalidValue;
@@ -1461,10 +1461,10 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
     if (q_forced > 0 && q_forced < Q) Q = q_forced;
   }
   if (Q * (nslabs > 0 ? nslabs : 1) < W) W = Q * (nslabs > 0 ? nslabs : 1);      // no more waves than tasks can ever be open
-  // one slot per CU (a 4096-point problem in float64-exact mode): its rounds of 8–16 tasks do not feed 16 waves, and the idle ones poll
+  // (builds without running sums) one slot per CU (a 4096-point problem in float64-exact mode): its rounds of 8–16 tasks do not feed 16 waves, and the idle ones poll
   // the LDS the working ones read (C4 float64-exact: 11.9 against 12.6 ms)
   if (Q == 1 && certify && W > 8 && !getenv("LSLAM_ICP_QUEUE_WAVES")) W = 8;
-  // fused tasks from the second iteration on: a second round of tasks per iteration only adds hand-offs (C4, three slots of eight tasks:
+  // (builds without running sums) fused tasks from the second iteration on: a second round of tasks per iteration only adds hand-offs (C4, three slots of eight tasks:
   // 5.60 -> 5.23 ms; float64-exact, two slots: 9.5 -> 9.0 ms)
   lay.fuse = env_int("LSLAM_ICP_QUEUE_FUSE", 1);
   lay.slot_bytes = (uint32_t)slot;
@@ -1524,7 +1524,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
     fprintf(stderr, "[lslam] icp_queue_kernel: %d workgroups x %d waves, %d slots of %zu B (%zu B LDS), %d rows per slot, %s\n",
             grid, W, Q, slot, smem, rows_cap, f64 ? (incr ? "float64-exact, running sums" : "float64-exact") : (incr ? "float32, running sums" : "float32"));
   }
-  hipError_t e = hipMemsetAsync(sc.queue, 0, 176, stream);      // (the counters of the debug print live in the first 136 bytes)
+  hipError_t e = hipMemsetAsync(sc.queue, 0, 176, stream);      // (draw counter, debug and profile counters: words 0 … 43; the class counts [48] [49] and the sticky give-up count [50] stay)
   if (e != hipSuccess) return e;
   auto launch = [&](auto kernel) -> hipError_t {
     hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
