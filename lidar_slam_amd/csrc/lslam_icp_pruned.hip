@@ -245,9 +245,14 @@ icp_sort_kernel(IcpBatchArgs a, PruneScratch sc, int len_pow2, int keep_forced, 
     float mx = 0.f;                                            // the largest |p|² of the source, for the queue kernel's step bound and near-tie window
     for (int i = tid; i < n; i += kSortThreads) { const float2 q = src[i]; pts[i] = q; mx = fmaxf(mx, __builtin_fmaf(q.y, q.y, q.x * q.x)); }
     mx = wave_max_f(mx);
-    if (sc.smax && (tid & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(&sc.smax[pair]), __float_as_uint(mx));      // (≥ 0: the bit patterns order as the values)
+    if ((tid & 63) == 0) red[tid >> 6][0] = mx;                // (red is free here: every earlier use ended at a barrier)
   }
   __syncthreads();
+  if (sc.smax && tid == 0) {
+    float mx = red[0][0];
+    for (int w = 1; w < kSortThreads / 64; ++w) mx = fmaxf(mx, red[w][0]);
+    sc.smax[pair] = mx;
+  }
   bool keep_src = keep_forced >= 0 ? (keep_forced & 2) != 0 : false;
   if (keep_forced < 0) {
     float u0, v0, u1, v1;
@@ -827,12 +832,8 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
       else skip64 = big >= kQueueCertifyPoints ? 1 : 0;
     }
   }
-  if (split) {
-    const hipError_t ee = hipMemsetAsync(sc.queue + 48, 0, 2 * sizeof(unsigned), stream);
-    if (ee != hipSuccess) return ee;
-  }
-  if (sc.smax) {
-    const hipError_t ee = hipMemsetAsync(sc.smax, 0, sizeof(float) * (size_t)S, stream);
+  if (split) {                                               // one memset for both launches: draw counters [0] [44], debug counters, class counts [48] [49] (not the sticky [50])
+    const hipError_t ee = hipMemsetAsync(sc.queue, 0, 50 * sizeof(unsigned), stream);
     if (ee != hipSuccess) return ee;
   }
   {
@@ -856,10 +857,10 @@ hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int6
     if (const char* env = getenv("LSLAM_ICP_PRUNE_QUEUE")) queue = atoi(env) != 0;
     if (queue && sc.queue) {
       if (!split) return launch_icp_queue(a, scs, S, max_src_n, max_tgt_n, stream);
-      const hipError_t ee = launch_icp_queue(a, scs, S, max_src_n, max_tgt_n, stream, 1);
+      const hipError_t ee = launch_icp_queue(a, scs, S, max_src_n, max_tgt_n, stream, 1, true);
       if (ee != hipSuccess) return ee;
       const int64_t cap_small = kQueueCertifyPoints - 1;
-      return launch_icp_queue(a, scs, S, max_src_n < cap_small ? max_src_n : cap_small, max_tgt_n < cap_small ? max_tgt_n : cap_small, stream, 0);
+      return launch_icp_queue(a, scs, S, max_src_n < cap_small ? max_src_n : cap_small, max_tgt_n < cap_small ? max_tgt_n : cap_small, stream, 0, true);
     }
   }
   // One source per lane, and about four slabs of 64 sources per wave: a workgroup is then a quarter of the waves a problem

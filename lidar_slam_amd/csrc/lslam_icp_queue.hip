@@ -347,7 +347,7 @@ icp_queue_kernel(IcpBatchArgs args, PruneScratch sc, QueueLayout lay, int S) {
   auto refill = [&](int q) {
     QueueCtl* c = ctl_of(q);
     int p = 0;
-    if (lane == 0) p = (int)atomicAdd(&lay.queue[0], 1u);
+    if (lane == 0) p = (int)atomicAdd(&lay.queue[lay.draw], 1u);
     p = __builtin_amdgcn_readfirstlane(p);
     // (a launch over one class of problems: their number was counted by icp_sort_kernel, their indices are in `order`)
     const int avail = lay.cls < 0 ? S : (int)__builtin_amdgcn_readfirstlane(__hip_atomic_load(&lay.queue[48 + lay.cls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -1395,7 +1395,7 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n, hipStream_t stream, int cls) {
+hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n, hipStream_t stream, int cls, bool counters_zeroed) {
   if ((a.src64 == nullptr) != (a.tgt64 == nullptr)) return hipErrorInvalidValue;
   const bool f64 = a.src64 != nullptr;
   const bool box = (a.flags & kFlagNormalize) != 0;
@@ -1484,6 +1484,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
   lay.timeout_ticks = kQTimeoutTicks;
   if (const char* e = getenv("LSLAM_ICP_QUEUE_TIMEOUT_US")) lay.timeout_ticks = (long long)(atof(e) * 100.0);      // (tests of the give-up path)
   lay.cls = cls; lay.order = sc.order;
+  lay.draw = cls == 0 ? 44 : 0;                               // the two launches of a split batch draw from counters of their own (zeroed together, before the sort)
   lay.margins = sc.margins;
   lay.margin_stride = (uint32_t)((max_src_n + 63) & ~(int64_t)63);
   if ((f64 || incr) && certify && (!sc.margins || (size_t)(S < cus ? S : cus) * 16 * lay.margin_stride * (incr ? 3 : 1) > sc.margin_cap)) return hipErrorInvalidValue;
@@ -1524,7 +1525,7 @@ hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64
     fprintf(stderr, "[lslam] icp_queue_kernel: %d workgroups x %d waves, %d slots of %zu B (%zu B LDS), %d rows per slot, %s\n",
             grid, W, Q, slot, smem, rows_cap, f64 ? (incr ? "float64-exact, running sums" : "float64-exact") : (incr ? "float32, running sums" : "float32"));
   }
-  hipError_t e = hipMemsetAsync(sc.queue, 0, 176, stream);      // (draw counter, debug and profile counters: words 0 … 43; the class counts [48] [49] and the sticky give-up count [50] stay)
+  hipError_t e = counters_zeroed ? hipSuccess : hipMemsetAsync(sc.queue, 0, 180, stream);      // (draw counter, debug and profile counters: words 0 … 43; the class counts [48] [49] and the sticky give-up count [50] stay)
   if (e != hipSuccess) return e;
   auto launch = [&](auto kernel) -> hipError_t {
     hipError_t ee = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -77,7 +77,7 @@ struct PruneScratch {                      // Morton-sorted copies: problem k ow
   // them sequentially / from neighbouring lines instead of gathering 16 bytes per point from the caller's order
   double2* src64_sorted; double2* tgt64_sorted;
   uint16_t* margins; size_t margin_cap;    // float64-exact mode, task-queue kernel: a row of margins (halves) per LDS slot of every workgroup; capacity in entries
-  float* smax;                             // per problem: the largest |p|² of its float32 source (icp_sort_kernel has the cloud in LDS anyway; zeroed before the sort)
+  float* smax;                             // per problem: the largest |p|² of its float32 source (icp_sort_kernel has the cloud in LDS anyway)
   int32_t* order;                          // problems by class, written by icp_sort_kernel: those below 2048 points per cloud from the front, the others from the back (queue[48], queue[49] count them)
   unsigned* queue;                         // 256 bytes: [0] next problem of the task-queue kernel, [1] waves that gave up waiting, [2] tie passes, [4…] profile, [48] [49] problems per class, [50] waves that gave up since the host last looked (never reset by a launch)
 };
@@ -95,12 +95,13 @@ struct QueueLayout {
   unsigned* queue;
   int32_t debug;
   long long timeout_ticks;                                         // idle waves leave after this many 100 MHz ticks without any sign of life in their workgroup (4 s)
+  int32_t draw;                                                    // word of `queue` the problems are drawn from
   int32_t cls;                                                     // −1: problems 0 … S−1; 0 / 1: the problems of that class (PruneScratch::order)
   const int32_t* order;
   uint16_t* margins; uint32_t margin_stride;                       // float64-exact mode: slot q of workgroup b keeps its margins at margins[(b·Q + q)·margin_stride …]
 };
 constexpr int64_t kQueueCertifyPoints = 2048;     // problems with a cloud this large keep matches on a proof and run on sums of changes (lslam_icp_queue.hip)
-hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n, hipStream_t stream, int cls = -1);
+hipError_t launch_icp_queue(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n, hipStream_t stream, int cls = -1, bool counters_zeroed = false);
 struct PruneLayout { uint32_t aabb_off, src_off, prev_off, red_off; unsigned* debug_counter; uint32_t slab_off; };   // slab_off: planar kernel only
 bool icp_pruned_supported(int dim, int64_t max_src_n, int64_t max_tgt_n);
 hipError_t launch_icp_pruned(IcpBatchArgs a, const PruneScratch& sc, int S, int64_t max_src_n, int64_t max_tgt_n,
